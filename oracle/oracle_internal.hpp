@@ -1,0 +1,73 @@
+// oracle/oracle_internal.hpp — shared state of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "aloam_oracle.h"
+#include "oracle_math.hpp"
+
+namespace orc {
+
+struct P4 { float x, y, z, i; };   // pcl::PointXYZI payload (reference include/aloam_velodyne/common.h:43)
+
+struct RegistrationResult {
+  std::vector<P4> cloud;                 // ring-ordered "laserCloud"   (scanRegistration.cpp:246-252)
+  std::vector<int> ring_start, ring_count;
+  std::vector<float> curvature;          // cloudCurvature              (scanRegistration.cpp:66,262)
+  std::vector<int> label, picked;        // cloudLabel / cloudNeighborPicked (scanRegistration.cpp:68-69)
+  std::vector<P4> sharp, less_sharp, flat, less_flat;
+};
+
+int register_scan(const orc_config& cfg, const void* pts, int n_in, int stride_bytes, RegistrationResult* out, std::string* err);
+void voxel_filter(const std::vector<P4>& in, float leaf, bool canonical, std::vector<P4>* out);
+float atan2f_port(float y, float x);
+
+// exact 1-NN over x,y,z with the f32 distance ((dx*dx+dy*dy)+dz*dz); lowest index wins ties.
+struct NnIndex {
+  std::vector<P4> pts;
+  std::vector<int> perm;      // kd-tree: point order
+  struct Node { int lo, hi, axis, left, right; float split; };
+  std::vector<Node> nodes;
+  void build(const std::vector<P4>& cloud);
+  void query(const P4& q, bool brute, int* idx, float* d2) const;
+ private:
+  int build_rec(int lo, int hi);
+  void search(int node, const float q[3], int* best, float* bestd) const;
+};
+
+struct EdgeRec { V3d cp, a, b; int query; };          // LidarEdgeFactor ctor args  (lidarFactor.hpp:14-16)
+struct PlaneRec { V3d cp, j, l, m; int query; };       // LidarPlaneFactor ctor args (lidarFactor.hpp:59-62)
+
+struct LmSummary { int iterations = 0, successful = 0, termination = 0; double initial_cost = 0, final_cost = 0; };
+
+void factor_eval_edge(const EdgeRec& e, const double q[4], const double t[3], bool analytic, double r[3], double J[18]);
+void factor_eval_plane(const PlaneRec& p, const double q[4], const double t[3], bool analytic, double r[1], double J[6]);
+double robust_cost(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec>& planes, const double q[4], const double t[3]);
+void quat_plus(const double q[4], const double delta[3], double out[4]);
+LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec>& planes, double q[4], double t[3],
+                   int max_iterations, bool analytic, bool apply_converged_step);
+
+struct OdomState {
+  double para_q[4] = {0, 0, 0, 1};        // laserOdometry.cpp:97
+  double para_t[3] = {0, 0, 0};           // laserOdometry.cpp:98
+  Quatd q_w{0, 0, 0, 1};                  // laserOdometry.cpp:93 (xyzw storage here)
+  V3d t_w{0, 0, 0};                       // laserOdometry.cpp:94
+  bool inited = false;                    // laserOdometry.cpp:69
+  std::vector<P4> corner_last, surf_last; // laserOdometry.cpp:85-86
+  NnIndex tree_corner, tree_surf;         // laserOdometry.cpp:77-78
+  std::vector<EdgeRec> edges;             // last outer iteration
+  std::vector<PlaneRec> planes;
+  orc_odom_stats stats{};
+};
+
+int odometry_step(const orc_config& cfg, const std::vector<P4>& sharp, const std::vector<P4>& less_sharp,
+                  const std::vector<P4>& flat, const std::vector<P4>& less_flat, OdomState* st, std::string* err);
+
+}  // namespace orc
+
+struct orc_ctx {
+  orc_config cfg;
+  orc::RegistrationResult reg;
+  orc::OdomState odom;
+  std::string err;
+};

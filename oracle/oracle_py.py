@@ -1,0 +1,227 @@
+"""ctypes binding of the CPU oracle (oracle/build/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — nowhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "liboracle.so")
+
+
+class OrcConfig(C.Structure):
+    _fields_ = [("n_scans", C.c_int), ("min_range", C.c_float), ("ring_from_field", C.c_int), ("canonical_order", C.c_int),
+                ("nn_brute", C.c_int), ("analytic_jacobian", C.c_int), ("apply_converged_step", C.c_int),
+                ("lm_max_iterations", C.c_int), ("outer_iterations", C.c_int)]
+
+
+class OrcOdomStats(C.Structure):
+    _fields_ = [("corner_corr", C.c_int * 2), ("plane_corr", C.c_int * 2), ("lm_iterations", C.c_int * 2),
+                ("lm_successful", C.c_int * 2), ("initial_cost", C.c_double * 2), ("final_cost", C.c_double * 2),
+                ("termination", C.c_int * 2)]
+
+
+CLOUD_FULL, CLOUD_SHARP, CLOUD_LESS_SHARP, CLOUD_FLAT, CLOUD_LESS_FLAT, CLOUD_CORNER_LAST, CLOUD_SURF_LAST = range(7)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with its Makefile (g++ only)."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp", ".h"))]
+    stale = force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, ip, fp, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)
+        L.orc_default_config.argtypes = [C.POINTER(OrcConfig)]
+        L.orc_create.argtypes = [C.POINTER(OrcConfig)]; L.orc_create.restype = vp
+        L.orc_destroy.argtypes = [vp]
+        L.orc_last_error.argtypes = [vp]; L.orc_last_error.restype = C.c_char_p
+        L.orc_scan_register.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.orc_cloud_size.argtypes = [vp, C.c_int]
+        L.orc_get_cloud.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.orc_get_ring_ranges.argtypes = [vp, vp, vp]
+        L.orc_get_curvature.argtypes = [vp, vp, C.c_int]
+        L.orc_get_labels.argtypes = [vp, vp, C.c_int]
+        L.orc_get_picked.argtypes = [vp, vp, C.c_int]
+        L.orc_set_features.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int]
+        L.orc_set_last.argtypes = [vp, vp, C.c_int, vp, C.c_int]
+        L.orc_set_state.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+        L.orc_odometry_step.argtypes = [vp]
+        L.orc_get_pose.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_get_odom_stats.argtypes = [vp, C.POINTER(OrcOdomStats)]
+        L.orc_get_correspondences.argtypes = [vp, vp, C.c_int, ip, vp, C.c_int, ip, vp, vp]
+        L.orc_voxel_filter.argtypes = [vp, C.c_int, C.c_float, C.c_int, vp, C.c_int]
+        L.orc_nn_search.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_factor_eval.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp]
+        L.orc_cost.argtypes = [C.c_int, vp, C.c_int, vp, vp, vp]; L.orc_cost.restype = C.c_double
+        L.orc_lm_solve.argtypes = [C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, ip]
+        L.orc_atan2f_port.argtypes = [C.c_float, C.c_float]; L.orc_atan2f_port.restype = C.c_float
+        L.orc_quat_plus.argtypes = [vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    """One sequence: scan registration + odometry state, mirroring the two reference nodes."""
+
+    def __init__(self, n_scans=64, min_range=5.0, ring_from_field=False, canonical_order=True, nn_brute=False,
+                 analytic_jacobian=False, apply_converged_step=False, lm_max_iterations=4, outer_iterations=2):
+        L = lib()
+        cfg = OrcConfig()
+        L.orc_default_config(C.byref(cfg))
+        cfg.n_scans, cfg.min_range, cfg.ring_from_field = n_scans, min_range, int(ring_from_field)
+        cfg.canonical_order, cfg.nn_brute, cfg.analytic_jacobian = int(canonical_order), int(nn_brute), int(analytic_jacobian)
+        cfg.apply_converged_step, cfg.lm_max_iterations, cfg.outer_iterations = int(apply_converged_step), lm_max_iterations, outer_iterations
+        self.cfg = cfg
+        self.n_scans = n_scans
+        self.h = L.orc_create(C.byref(cfg))
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            try:
+                _lib.orc_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+    def scan_register(self, pts):
+        pts = _f32(pts)
+        assert pts.ndim == 2 and pts.shape[1] >= 4
+        rc = lib().orc_scan_register(self.h, _p(pts), pts.shape[0], pts.strides[0])
+        if rc != 0:
+            raise RuntimeError(lib().orc_last_error(self.h).decode())
+        return self.features()
+
+    def cloud(self, which):
+        n = lib().orc_cloud_size(self.h, which)
+        out = np.zeros((max(n, 0), 4), np.float32)
+        lib().orc_get_cloud(self.h, which, _p(out), n)
+        return out
+
+    def features(self):
+        return {"cloud": self.cloud(CLOUD_FULL), "sharp": self.cloud(CLOUD_SHARP), "less_sharp": self.cloud(CLOUD_LESS_SHARP),
+                "flat": self.cloud(CLOUD_FLAT), "less_flat": self.cloud(CLOUD_LESS_FLAT)}
+
+    def ring_ranges(self):
+        s = np.zeros(self.n_scans, np.int32); c = np.zeros(self.n_scans, np.int32)
+        lib().orc_get_ring_ranges(self.h, _p(s), _p(c))
+        return s, c
+
+    def per_point(self):
+        n = lib().orc_cloud_size(self.h, CLOUD_FULL)
+        curv = np.zeros(n, np.float32); lab = np.zeros(n, np.int32); pk = np.zeros(n, np.int32)
+        lib().orc_get_curvature(self.h, _p(curv), n)
+        lib().orc_get_labels(self.h, _p(lab), n)
+        lib().orc_get_picked(self.h, _p(pk), n)
+        return curv, lab, pk
+
+    def set_features(self, f):
+        a = [_f32(f[k]) for k in ("sharp", "less_sharp", "flat", "less_flat")]
+        lib().orc_set_features(self.h, _p(a[0]), len(a[0]), _p(a[1]), len(a[1]), _p(a[2]), len(a[2]), _p(a[3]), len(a[3]))
+
+    def set_last(self, corner_last, surf_last):
+        a, b = _f32(corner_last), _f32(surf_last)
+        lib().orc_set_last(self.h, _p(a), len(a), _p(b), len(b))
+
+    def set_state(self, para_q, para_t, q_w=(0, 0, 0, 1), t_w=(0, 0, 0), inited=True):
+        a, b, c, d = _f64(para_q), _f64(para_t), _f64(q_w), _f64(t_w)
+        lib().orc_set_state(self.h, _p(a), _p(b), _p(c), _p(d), int(inited))
+
+    def odometry_step(self):
+        rc = lib().orc_odometry_step(self.h)
+        if rc != 0:
+            raise RuntimeError(lib().orc_last_error(self.h).decode())
+        return self.pose()
+
+    def pose(self):
+        qw, tw, ql, tl = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        lib().orc_get_pose(self.h, _p(qw), _p(tw), _p(ql), _p(tl))
+        return {"q_w": qw, "t_w": tw, "q_lc": ql, "t_lc": tl}
+
+    def odom_stats(self):
+        st = OrcOdomStats()
+        lib().orc_get_odom_stats(self.h, C.byref(st))
+        return {k: list(getattr(st, k)) for k, _ in OrcOdomStats._fields_}
+
+    def correspondences(self):
+        cap_e, cap_p = 16384, 32768
+        e = np.zeros((cap_e, 9)); p = np.zeros((cap_p, 12))
+        ne, npl = C.c_int(0), C.c_int(0)
+        eq = np.zeros(cap_e, np.int32); pq = np.zeros(cap_p, np.int32)
+        lib().orc_get_correspondences(self.h, _p(e), cap_e, C.byref(ne), _p(p), cap_p, C.byref(npl), _p(eq), _p(pq))
+        return e[:ne.value].copy(), p[:npl.value].copy(), eq[:ne.value].copy(), pq[:npl.value].copy()
+
+
+def voxel_filter(xyzi, leaf, canonical=True):
+    a = _f32(xyzi)
+    out = np.zeros_like(a)
+    n = lib().orc_voxel_filter(_p(a), len(a), leaf, int(canonical), _p(out), len(a))
+    return out[:n].copy()
+
+
+def nn_search(target, query, brute=False):
+    t, q = _f32(target), _f32(query)
+    idx = np.zeros(len(q), np.int32); d2 = np.zeros(len(q), np.float32)
+    lib().orc_nn_search(_p(t), len(t), _p(q), len(q), int(brute), _p(idx), _p(d2))
+    return idx, d2
+
+
+def factor_eval(kind, consts, q, t, analytic):
+    c, q, t = _f64(consts), _f64(q), _f64(t)
+    rows = 3 if kind == 0 else 1
+    r = np.zeros(rows); J = np.zeros((rows, 6))
+    lib().orc_factor_eval(kind, _p(c), _p(q), _p(t), int(analytic), _p(r), _p(J))
+    return r, J
+
+
+def cost(edges, planes, q, t):
+    e, p, q, t = _f64(edges).reshape(-1, 9), _f64(planes).reshape(-1, 12), _f64(q), _f64(t)
+    return lib().orc_cost(len(e), _p(e), len(p), _p(p), _p(q), _p(t))
+
+
+def lm_solve(edges, planes, q, t, max_iterations=4, analytic=False, apply_converged_step=False):
+    e, p = _f64(edges).reshape(-1, 9), _f64(planes).reshape(-1, 12)
+    q, t = _f64(q).copy(), _f64(t).copy()
+    it, su, term = C.c_int(0), C.c_int(0), C.c_int(0)
+    c0, c1 = C.c_double(0), C.c_double(0)
+    lib().orc_lm_solve(len(e), _p(e), len(p), _p(p), _p(q), _p(t), max_iterations, int(analytic), int(apply_converged_step),
+                       C.byref(it), C.byref(su), C.byref(c0), C.byref(c1), C.byref(term))
+    return q, t, {"iterations": it.value, "successful": su.value, "initial_cost": c0.value, "final_cost": c1.value, "termination": term.value}
+
+
+def atan2f_port(y, x):
+    return lib().orc_atan2f_port(float(y), float(x))
+
+
+def quat_plus(q, delta):
+    q, d, out = _f64(q), _f64(delta), np.zeros(4)
+    lib().orc_quat_plus(_p(q), _p(d), _p(out))
+    return out
