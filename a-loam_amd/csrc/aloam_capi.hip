@@ -1,0 +1,560 @@
+// a-loam_amd/csrc/aloam_capi.hip — host side of libaloam_mi355x.so: context, device buffers, launch sequencing and
+// the extern "C" surface declared in include/aloam_mi355x.h.  There is no CPU fallback anywhere in this file:
+// without a HIP device every entry point fails with ALOAM_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/aloam_mi355x.h"
+#include "aloam_device.hpp"
+#include "odometry_kernels.hpp"
+#include "registration_kernels.hpp"
+
+using namespace aloam;
+
+namespace {
+enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_COMPACT, K_NN_CORNER, K_NN_PLANE,
+                K_WALK_CORNER, K_WALK_PLANE, K_SOLVE, K_ADVANCE, K_COUNT };
+const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_classify", "k_ring_offsets", "k_scatter", "k_ring_features",
+                                     "k_compact_features", "k_nn_search[corner]", "k_nn_search[plane]", "k_walk_corner",
+                                     "k_walk_plane", "k_solve", "k_advance"};
+struct ProfRec { int kernel; hipEvent_t e0, e1; };
+}  // namespace
+
+struct aloam_ctx {
+  aloam_config cfg{};
+  int B = 0, cap = 0, R = 0, NB = 0, npad = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // input staging (host-input path only)
+  char* d_in = nullptr; size_t d_in_bytes = 0;
+  char* h_pin = nullptr; size_t h_pin_bytes = 0;
+  int* d_nin = nullptr; std::vector<int> h_nin;   // pageable on purpose: the async H2D copy stages it before returning
+  SeqMeta* d_meta = nullptr;
+  int8_t* d_ringid = nullptr; float* d_ori = nullptr;
+  int *d_hist = nullptr, *d_blockoff = nullptr, *d_ringstart = nullptr;
+  float4* d_cloud = nullptr; float* d_curv = nullptr; int8_t* d_label = nullptr;
+  int *d_sharp_idx = nullptr, *d_less_sharp_idx = nullptr, *d_flat_idx = nullptr, *d_pick_cnt = nullptr;
+  float4* d_lf_ring = nullptr; int* d_lf_cnt = nullptr;
+  float4 *d_sharp = nullptr, *d_flat = nullptr;
+  float4* d_less_sharp[2] = {nullptr, nullptr};
+  float4* d_less_flat[2] = {nullptr, nullptr};
+  int cur = 0;                       // which of the double buffers holds the CURRENT sweep's less-sharp / less-flat
+  OdomState* d_state = nullptr;
+  unsigned long long *d_nn_corner = nullptr, *d_nn_surf = nullptr;
+  EdgeRec* d_edges = nullptr; PlaneRec* d_planes = nullptr;
+  bool system_inited = false;        // reference src/laserOdometry.cpp:69
+  bool have_features = false;
+  // profiling
+  bool prof_on = false;
+  std::vector<ProfRec> prof_pending;
+  std::vector<hipEvent_t> prof_free;
+  double prof_ms[K_COUNT] = {0};
+  long long prof_launches[K_COUNT] = {0};
+};
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+  do {                                                                                                       \
+    hipError_t e__ = (expr);                                                                                 \
+    if (e__ != hipSuccess) {                                                                                 \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                                       \
+      return ALOAM_E_HIP;                                                                                    \
+    }                                                                                                        \
+  } while (0)
+
+namespace {
+
+template <typename T>
+int dmalloc(aloam_ctx* c, T** p, size_t count) {
+  HIP_TRY(c, hipMalloc((void**)p, count * sizeof(T)));
+  HIP_TRY(c, hipMemsetAsync(*p, 0, count * sizeof(T), c->stream));
+  return ALOAM_OK;
+}
+
+hipEvent_t prof_event(aloam_ctx* c) {
+  if (!c->prof_free.empty()) { hipEvent_t e = c->prof_free.back(); c->prof_free.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+struct ProfScope {
+  aloam_ctx* c; int k; hipEvent_t e0 = nullptr;
+  ProfScope(aloam_ctx* c_, int k_) : c(c_), k(k_) {
+    if (c->prof_on) { e0 = prof_event(c); (void)hipEventRecord(e0, c->stream); }
+  }
+  ~ProfScope() {
+    if (c->prof_on) { hipEvent_t e1 = prof_event(c); (void)hipEventRecord(e1, c->stream); c->prof_pending.push_back({k, e0, e1}); }
+  }
+};
+void prof_resolve(aloam_ctx* c) {
+  for (ProfRec& r : c->prof_pending) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(r.e1);
+    (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    c->prof_ms[r.kernel] += ms;
+    c->prof_launches[r.kernel] += 1;
+    c->prof_free.push_back(r.e0);
+    c->prof_free.push_back(r.e1);
+  }
+  c->prof_pending.clear();
+}
+
+RegArgs reg_args(aloam_ctx* c, const void* d_scans, long long seq_stride, int pt_stride) {
+  RegArgs a{};
+  a.in = (const char*)d_scans; a.seq_stride = seq_stride; a.pt_stride = pt_stride;
+  a.B = c->B; a.cap = c->cap; a.R = c->R; a.NB = c->NB;
+  a.ring_from_field = c->cfg.ring_from_field; a.min_range = c->cfg.min_range;
+  a.meta = c->d_meta; a.ringid = c->d_ringid; a.ori = c->d_ori; a.hist = c->d_hist; a.blockoff = c->d_blockoff;
+  a.ringstart = c->d_ringstart; a.cloud = c->d_cloud; a.curv = c->d_curv; a.label = c->d_label;
+  a.sharp_idx = c->d_sharp_idx; a.less_sharp_idx = c->d_less_sharp_idx; a.flat_idx = c->d_flat_idx; a.pick_cnt = c->d_pick_cnt;
+  a.lf_ring = c->d_lf_ring; a.lf_cnt = c->d_lf_cnt;
+  a.sharp = c->d_sharp; a.less_sharp = c->d_less_sharp[c->cur]; a.flat = c->d_flat; a.less_flat = c->d_less_flat[c->cur];
+  return a;
+}
+
+OdomArgs odom_args(aloam_ctx* c) {
+  OdomArgs a{};
+  a.B = c->B; a.cap = c->cap; a.R = c->R;
+  a.meta = c->d_meta; a.state = c->d_state;
+  a.sharp = c->d_sharp; a.flat = c->d_flat;
+  a.corner_last = c->d_less_sharp[1 - c->cur]; a.surf_last = c->d_less_flat[1 - c->cur];
+  a.nn_corner = c->d_nn_corner; a.nn_surf = c->d_nn_surf; a.edges = c->d_edges; a.planes = c->d_planes;
+  a.lm_max_iterations = c->cfg.lm_max_iterations;
+  return a;
+}
+
+int check_seq(aloam_ctx* c, int seq) {
+  if (!c) return ALOAM_E_ARG;
+  if (seq < 0 || seq >= c->B) { c->err = "sequence index out of range"; return ALOAM_E_ARG; }
+  return ALOAM_OK;
+}
+
+int sync_and_check(aloam_ctx* c) {
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ALOAM_OK;
+}
+
+int fetch_meta(aloam_ctx* c, int seq, SeqMeta* m) {
+  HIP_TRY(c, hipMemcpyAsync(m, c->d_meta + seq, sizeof(SeqMeta), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ALOAM_OK;
+}
+
+int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, const int* n_in, int stride_bytes) {
+  if (stride_bytes < 16 || (stride_bytes & 3)) { c->err = "stride_bytes must be >= 16 and a multiple of 4"; return ALOAM_E_ARG; }
+  for (int b = 0; b < c->B; ++b) {
+    if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
+    if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
+    c->h_nin[b] = n_in[b];
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_nin, c->h_nin.data(), sizeof(int) * c->B, hipMemcpyHostToDevice, c->stream));
+  const RegArgs a = reg_args(c, d_scans, seq_stride, stride_bytes);
+  { ProfScope p(c, K_FIND_ENDS); launch_find_ends(a, c->d_nin, c->stream); }
+  { ProfScope p(c, K_CLASSIFY); launch_classify(a, c->stream); }
+  { ProfScope p(c, K_RING_OFFSETS); launch_ring_offsets(a, c->stream); }
+  { ProfScope p(c, K_SCATTER); launch_scatter(a, c->stream); }
+  { ProfScope p(c, K_RING_FEATURES); launch_ring_features(a, c->npad, 0.2f, c->stream); }   // leaf 0.2 (src/scanRegistration.cpp:404)
+  { ProfScope p(c, K_COMPACT); launch_compact_features(a, c->stream); }
+  HIP_TRY(c, hipGetLastError());
+  c->have_features = true;
+  return ALOAM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void aloam_default_config(aloam_config* cfg) {
+  cfg->n_scans = 64;            // launch/aloam_velodyne_HDL_64.launch: scan_line
+  cfg->min_range = 5.0f;        // launch/aloam_velodyne_HDL_64.launch: minimum_range
+  cfg->ring_from_field = 0;
+  cfg->batch = 1;
+  cfg->max_points = 140000;
+  cfg->max_ring_points = 4107;
+  cfg->device = 0;
+  cfg->lm_max_iterations = 4;
+  cfg->outer_iterations = 2;
+}
+
+int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
+  if (!cfg || !out) return ALOAM_E_ARG;
+  *out = nullptr;
+  aloam_ctx* c = new aloam_ctx();
+  c->cfg = *cfg;
+  *out = c;   // returned even on failure so that aloam_last_error() works; caller destroys it
+  if (cfg->batch < 1 || cfg->max_points < 32 || cfg->max_points > 400000 || cfg->lm_max_iterations < 0 || cfg->outer_iterations < 1 ||
+      cfg->outer_iterations > 2) { c->err = "bad configuration value"; return ALOAM_E_ARG; }
+  if (!cfg->ring_from_field && cfg->n_scans != 16 && cfg->n_scans != 32 && cfg->n_scans != 64) {
+    c->err = "only support velodyne with 16, 32 or 64 scan line (or ring_from_field)";   // src/scanRegistration.cpp:472-476
+    return ALOAM_E_SCAN_LINES;
+  }
+  if (cfg->n_scans < 1 || cfg->n_scans > kMaxRings) { c->err = "n_scans out of range"; return ALOAM_E_ARG; }
+  if (cfg->max_ring_points < 17 || cfg->max_ring_points > 4107) { c->err = "max_ring_points must be in [17, 4107]"; return ALOAM_E_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device available (this library has no CPU fallback)"; return ALOAM_E_HIP; }
+  HIP_TRY(c, hipSetDevice(cfg->device));
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  c->B = cfg->batch; c->cap = cfg->max_points; c->R = cfg->n_scans;
+  c->NB = (c->cap + kBlockPts - 1) / kBlockPts;
+  c->npad = cfg->max_ring_points <= 2059 ? 2048 : 4096;
+  const size_t B = c->B, cap = c->cap, R = c->R, NB = c->NB;
+  int rc = 0;
+  c->h_nin.assign(B, 0);
+  if ((rc = dmalloc(c, &c->d_nin, B))) return rc;
+  if ((rc = dmalloc(c, &c->d_meta, B))) return rc;
+  if ((rc = dmalloc(c, &c->d_ringid, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_ori, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_hist, B * NB * R))) return rc;
+  if ((rc = dmalloc(c, &c->d_blockoff, B * NB * R))) return rc;
+  if ((rc = dmalloc(c, &c->d_ringstart, B * (R + 1)))) return rc;
+  if ((rc = dmalloc(c, &c->d_cloud, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_curv, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_label, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_sharp_idx, B * R * kSectors * kSharpPerSector))) return rc;
+  if ((rc = dmalloc(c, &c->d_less_sharp_idx, B * R * kSectors * kLessSharpPerSector))) return rc;
+  if ((rc = dmalloc(c, &c->d_flat_idx, B * R * kSectors * kFlatPerSector))) return rc;
+  if ((rc = dmalloc(c, &c->d_pick_cnt, B * R * kSectors * 3))) return rc;
+  if ((rc = dmalloc(c, &c->d_lf_ring, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_lf_cnt, B * R))) return rc;
+  if ((rc = dmalloc(c, &c->d_sharp, B * R * 12))) return rc;
+  if ((rc = dmalloc(c, &c->d_flat, B * R * 24))) return rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = dmalloc(c, &c->d_less_sharp[k], B * R * 120))) return rc;
+    if ((rc = dmalloc(c, &c->d_less_flat[k], B * cap))) return rc;
+  }
+  if ((rc = dmalloc(c, &c->d_state, B))) return rc;
+  if ((rc = dmalloc(c, &c->d_nn_corner, B * R * 12))) return rc;
+  if ((rc = dmalloc(c, &c->d_nn_surf, B * R * 24))) return rc;
+  if ((rc = dmalloc(c, &c->d_edges, B * R * 12))) return rc;
+  if ((rc = dmalloc(c, &c->d_planes, B * R * 24))) return rc;
+  // identity poses (src/laserOdometry.cpp:93-98)
+  std::vector<OdomState> init(B);
+  std::memset(init.data(), 0, sizeof(OdomState) * B);
+  for (size_t b = 0; b < B; ++b) { init[b].para_q[3] = 1.0; init[b].q_w[3] = 1.0; }
+  HIP_TRY(c, hipMemcpyAsync(c->d_state, init.data(), sizeof(OdomState) * B, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return ALOAM_OK;
+}
+
+void aloam_destroy(aloam_ctx* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  prof_resolve(c);
+  for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
+  void* bufs[] = {c->d_in, c->d_nin, c->d_meta, c->d_ringid, c->d_ori, c->d_hist, c->d_blockoff, c->d_ringstart, c->d_cloud, c->d_curv,
+                  c->d_label, c->d_sharp_idx, c->d_less_sharp_idx, c->d_flat_idx, c->d_pick_cnt, c->d_lf_ring, c->d_lf_cnt, c->d_sharp,
+                  c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_nn_corner,
+                  c->d_nn_surf, c->d_edges, c->d_planes};
+  for (void* p : bufs) if (p) (void)hipFree(p);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* aloam_last_error(const aloam_ctx* c) { return c ? c->err.c_str() : "null context"; }
+void* aloam_stream(aloam_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int aloam_synchronize(aloam_ctx* c) {
+  if (!c) return ALOAM_E_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::vector<SeqMeta> m(c->B);
+  HIP_TRY(c, hipMemcpy(m.data(), c->d_meta, sizeof(SeqMeta) * c->B, hipMemcpyDeviceToHost));
+  for (int b = 0; b < c->B; ++b) {
+    if (m[b].err & kErrEmpty) { c->err = "sequence " + std::to_string(b) + ": no point survives the NaN / minimum-range filter"; return ALOAM_E_EMPTY; }
+    if (m[b].err & (kErrRingCap | kErrPointCap)) { c->err = "sequence " + std::to_string(b) + ": a ring exceeds max_ring_points or the scan exceeds max_points"; return ALOAM_E_CAPACITY; }
+  }
+  return ALOAM_OK;
+}
+
+int aloam_scan_register_device(aloam_ctx* c, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
+  if (!c || !d_scans || !n_in) return ALOAM_E_ARG;
+  return register_launch(c, d_scans, seq_stride_bytes, n_in, stride_bytes);
+}
+
+int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in, int stride_bytes) {
+  if (!c || !scans || !n_in) return ALOAM_E_ARG;
+  if (stride_bytes < 16) { c->err = "stride_bytes must be >= 16"; return ALOAM_E_ARG; }
+  const size_t seq_stride = (size_t)c->cap * stride_bytes;
+  const size_t need = seq_stride * c->B;
+  if (c->d_in_bytes < need) {
+    if (c->d_in) HIP_TRY(c, hipFree(c->d_in));
+    HIP_TRY(c, hipMalloc((void**)&c->d_in, need));
+    c->d_in_bytes = need;
+  }
+  for (int b = 0; b < c->B; ++b) {
+    if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
+    if (n_in[b] > 0) HIP_TRY(c, hipMemcpyAsync(c->d_in + b * seq_stride, scans[b], (size_t)n_in[b] * stride_bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  const int rc = register_launch(c, c->d_in, (long long)seq_stride, n_in, stride_bytes);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // the host buffers may be reused on return
+  return ALOAM_OK;
+}
+
+int aloam_odometry_step(aloam_ctx* c) {
+  if (!c) return ALOAM_E_ARG;
+  if (!c->have_features) { c->err = "aloam_odometry_step before any features were registered / set"; return ALOAM_E_STATE; }
+  if (!c->system_inited) {
+    c->system_inited = true;                       // first frame: no solve (src/laserOdometry.cpp:267-271)
+  } else {
+    OdomArgs a = odom_args(c);
+    const int max_sharp = c->R * 12, max_flat = c->R * 24;
+    for (int outer = 0; outer < c->cfg.outer_iterations; ++outer) {
+      a.outer = outer;
+      a.last_outer = outer == c->cfg.outer_iterations - 1;
+      HIP_TRY(c, hipMemsetAsync(c->d_nn_corner, 0xff, sizeof(unsigned long long) * c->B * max_sharp, c->stream));
+      HIP_TRY(c, hipMemsetAsync(c->d_nn_surf, 0xff, sizeof(unsigned long long) * c->B * max_flat, c->stream));
+      { ProfScope p(c, K_NN_CORNER); launch_nn_search(a, 0, max_sharp, c->R * 120, c->stream); }
+      { ProfScope p(c, K_NN_PLANE); launch_nn_search(a, 1, max_flat, c->cap, c->stream); }
+      { ProfScope p(c, K_WALK_CORNER); launch_walk_corner(a, max_sharp, c->stream); }
+      { ProfScope p(c, K_WALK_PLANE); launch_walk_plane(a, max_flat, c->stream); }
+      { ProfScope p(c, K_SOLVE); launch_solve(a, c->stream); }
+    }
+  }
+  { ProfScope p(c, K_ADVANCE); launch_advance(c->d_meta, c->B, c->stream); }     // swap (src/laserOdometry.cpp:554-563)
+  HIP_TRY(c, hipGetLastError());
+  c->cur ^= 1;
+  return ALOAM_OK;
+}
+
+int aloam_process_device(aloam_ctx* c, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
+  const int rc = aloam_scan_register_device(c, d_scans, seq_stride_bytes, n_in, stride_bytes);
+  if (rc) return rc;
+  return aloam_odometry_step(c);
+}
+
+// ---- results ---------------------------------------------------------------------------------------------
+static int cloud_ref(aloam_ctx* c, int seq, int which, const SeqMeta& m, const float4** ptr, int* n) {
+  const size_t b = seq;
+  // aloam_odometry_step ends with the reference's pointer swap (src/laserOdometry.cpp:554-560): afterwards the sweep
+  // just processed is read through CORNER_LAST / SURF_LAST, exactly like laserCloudCornerLast / laserCloudSurfLast.
+  switch (which) {
+    case ALOAM_CLOUD_FULL: *ptr = c->d_cloud + b * c->cap; *n = m.n_cloud; return 0;
+    case ALOAM_CLOUD_SHARP: *ptr = c->d_sharp + b * c->R * 12; *n = m.n_sharp; return 0;
+    case ALOAM_CLOUD_FLAT: *ptr = c->d_flat + b * c->R * 24; *n = m.n_flat; return 0;
+    case ALOAM_CLOUD_LESS_SHARP: *ptr = c->d_less_sharp[c->cur] + b * c->R * 120; *n = m.n_less_sharp; return 0;
+    case ALOAM_CLOUD_LESS_FLAT: *ptr = c->d_less_flat[c->cur] + b * c->cap; *n = m.n_less_flat; return 0;
+    case ALOAM_CLOUD_CORNER_LAST: *ptr = c->d_less_sharp[1 - c->cur] + b * c->R * 120; *n = m.n_corner_last; return 0;
+    case ALOAM_CLOUD_SURF_LAST: *ptr = c->d_less_flat[1 - c->cur] + b * c->cap; *n = m.n_surf_last; return 0;
+  }
+  return -1;
+}
+
+int aloam_cloud_size(aloam_ctx* c, int seq, int which) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  SeqMeta m;
+  if ((rc = fetch_meta(c, seq, &m))) return rc;
+  const float4* p; int n;
+  if (cloud_ref(c, seq, which, m, &p, &n)) { c->err = "unknown cloud id"; return ALOAM_E_ARG; }
+  return n;
+}
+
+int aloam_get_cloud(aloam_ctx* c, int seq, int which, float* out, int cap_points) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  SeqMeta m;
+  if ((rc = fetch_meta(c, seq, &m))) return rc;
+  const float4* p; int n;
+  if (cloud_ref(c, seq, which, m, &p, &n)) { c->err = "unknown cloud id"; return ALOAM_E_ARG; }
+  const int k = n < cap_points ? n : cap_points;
+  if (k > 0) HIP_TRY(c, hipMemcpy(out, p, sizeof(float4) * k, hipMemcpyDeviceToHost));
+  return n;
+}
+
+int aloam_get_pose(aloam_ctx* c, int seq, double q_w[4], double t_w[3], double q_lc[4], double t_lc[3]) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if ((rc = sync_and_check(c))) return rc;
+  OdomState s;
+  HIP_TRY(c, hipMemcpy(&s, c->d_state + seq, sizeof(OdomState), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 4; ++k) { q_w[k] = s.q_w[k]; q_lc[k] = s.para_q[k]; }
+  for (int k = 0; k < 3; ++k) { t_w[k] = s.t_w[k]; t_lc[k] = s.para_t[k]; }
+  return ALOAM_OK;
+}
+
+int aloam_get_odom_stats(aloam_ctx* c, int seq, aloam_odom_stats* out) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if ((rc = sync_and_check(c))) return rc;
+  OdomState s;
+  HIP_TRY(c, hipMemcpy(&s, c->d_state + seq, sizeof(OdomState), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 2; ++k) {
+    out->corner_corr[k] = s.corner_corr[k]; out->plane_corr[k] = s.plane_corr[k];
+    out->lm_iterations[k] = s.lm_iterations[k]; out->lm_successful[k] = s.lm_successful[k];
+    out->initial_cost[k] = s.initial_cost[k]; out->final_cost[k] = s.final_cost[k]; out->termination[k] = s.termination[k];
+  }
+  return ALOAM_OK;
+}
+
+// ---- state injection -----------------------------------------------------------------------------------------
+int aloam_set_features(aloam_ctx* c, int seq, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp,
+                       const float* flat, int n_flat, const float* less_flat, int n_less_flat) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if (n_sharp < 0 || n_sharp > c->R * 12 || n_less_sharp < 0 || n_less_sharp > c->R * 120 || n_flat < 0 || n_flat > c->R * 24 ||
+      n_less_flat < 0 || n_less_flat > c->cap) { c->err = "feature cloud larger than the selection rules allow"; return ALOAM_E_CAPACITY; }
+  const size_t b = seq;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (n_sharp) HIP_TRY(c, hipMemcpy(c->d_sharp + b * c->R * 12, sharp, sizeof(float4) * n_sharp, hipMemcpyHostToDevice));
+  if (n_less_sharp) HIP_TRY(c, hipMemcpy(c->d_less_sharp[c->cur] + b * c->R * 120, less_sharp, sizeof(float4) * n_less_sharp, hipMemcpyHostToDevice));
+  if (n_flat) HIP_TRY(c, hipMemcpy(c->d_flat + b * c->R * 24, flat, sizeof(float4) * n_flat, hipMemcpyHostToDevice));
+  if (n_less_flat) HIP_TRY(c, hipMemcpy(c->d_less_flat[c->cur] + b * c->cap, less_flat, sizeof(float4) * n_less_flat, hipMemcpyHostToDevice));
+  SeqMeta m;
+  HIP_TRY(c, hipMemcpy(&m, c->d_meta + seq, sizeof(SeqMeta), hipMemcpyDeviceToHost));
+  m.n_sharp = n_sharp; m.n_less_sharp = n_less_sharp; m.n_flat = n_flat; m.n_less_flat = n_less_flat; m.err = 0;
+  HIP_TRY(c, hipMemcpy(c->d_meta + seq, &m, sizeof(SeqMeta), hipMemcpyHostToDevice));
+  c->have_features = true;
+  return ALOAM_OK;
+}
+
+int aloam_set_last(aloam_ctx* c, int seq, const float* corner_last, int n_corner, const float* surf_last, int n_surf) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if (n_corner < 0 || n_corner > c->R * 120 || n_surf < 0 || n_surf > c->cap) { c->err = "last cloud too large"; return ALOAM_E_CAPACITY; }
+  const size_t b = seq;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (n_corner) HIP_TRY(c, hipMemcpy(c->d_less_sharp[1 - c->cur] + b * c->R * 120, corner_last, sizeof(float4) * n_corner, hipMemcpyHostToDevice));
+  if (n_surf) HIP_TRY(c, hipMemcpy(c->d_less_flat[1 - c->cur] + b * c->cap, surf_last, sizeof(float4) * n_surf, hipMemcpyHostToDevice));
+  SeqMeta m;
+  HIP_TRY(c, hipMemcpy(&m, c->d_meta + seq, sizeof(SeqMeta), hipMemcpyDeviceToHost));
+  m.n_corner_last = n_corner; m.n_surf_last = n_surf;
+  HIP_TRY(c, hipMemcpy(c->d_meta + seq, &m, sizeof(SeqMeta), hipMemcpyHostToDevice));
+  return ALOAM_OK;
+}
+
+int aloam_set_state(aloam_ctx* c, int seq, const double para_q[4], const double para_t[3], const double q_w[4], const double t_w[3]) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  OdomState s;
+  HIP_TRY(c, hipMemcpy(&s, c->d_state + seq, sizeof(OdomState), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 4; ++k) { s.para_q[k] = para_q[k]; s.q_w[k] = q_w[k]; }
+  for (int k = 0; k < 3; ++k) { s.para_t[k] = para_t[k]; s.t_w[k] = t_w[k]; }
+  HIP_TRY(c, hipMemcpy(c->d_state + seq, &s, sizeof(OdomState), hipMemcpyHostToDevice));
+  return ALOAM_OK;
+}
+
+int aloam_set_system_inited(aloam_ctx* c, int inited) {
+  if (!c) return ALOAM_E_ARG;
+  c->system_inited = inited != 0;
+  return ALOAM_OK;
+}
+
+// ---- intermediate arrays ---------------------------------------------------------------------------------------
+int aloam_get_ring_ranges(aloam_ctx* c, int seq, int* start, int* count) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if ((rc = sync_and_check(c))) return rc;
+  std::vector<int> rs(c->R + 1);
+  HIP_TRY(c, hipMemcpy(rs.data(), c->d_ringstart + (size_t)seq * (c->R + 1), sizeof(int) * (c->R + 1), hipMemcpyDeviceToHost));
+  for (int r = 0; r < c->R; ++r) { start[r] = rs[r]; count[r] = rs[r + 1] - rs[r]; }
+  return c->R;
+}
+
+int aloam_get_curvature(aloam_ctx* c, int seq, float* out, int cap) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  SeqMeta m;
+  if ((rc = fetch_meta(c, seq, &m))) return rc;
+  const int k = m.n_cloud < cap ? m.n_cloud : cap;
+  if (k > 0) HIP_TRY(c, hipMemcpy(out, c->d_curv + (size_t)seq * c->cap, sizeof(float) * k, hipMemcpyDeviceToHost));
+  return m.n_cloud;
+}
+
+int aloam_get_labels(aloam_ctx* c, int seq, int* out, int cap) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  SeqMeta m;
+  if ((rc = fetch_meta(c, seq, &m))) return rc;
+  const int k = m.n_cloud < cap ? m.n_cloud : cap;
+  std::vector<int8_t> tmp(k > 0 ? k : 1);
+  if (k > 0) HIP_TRY(c, hipMemcpy(tmp.data(), c->d_label + (size_t)seq * c->cap, k, hipMemcpyDeviceToHost));
+  for (int i = 0; i < k; ++i) out[i] = tmp[i];
+  return m.n_cloud;
+}
+
+int aloam_get_correspondences(aloam_ctx* c, int seq, float* edges, int cap_edges, int* n_edges, int* edge_query,
+                              float* planes, int cap_planes, int* n_planes, int* plane_query) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  SeqMeta m;
+  if ((rc = fetch_meta(c, seq, &m))) return rc;
+  std::vector<EdgeRec> E(m.n_sharp > 0 ? m.n_sharp : 1);
+  std::vector<PlaneRec> P(m.n_flat > 0 ? m.n_flat : 1);
+  if (m.n_sharp > 0) HIP_TRY(c, hipMemcpy(E.data(), c->d_edges + (size_t)seq * c->R * 12, sizeof(EdgeRec) * m.n_sharp, hipMemcpyDeviceToHost));
+  if (m.n_flat > 0) HIP_TRY(c, hipMemcpy(P.data(), c->d_planes + (size_t)seq * c->R * 24, sizeof(PlaneRec) * m.n_flat, hipMemcpyDeviceToHost));
+  int ne = 0, np = 0;
+  for (int i = 0; i < m.n_sharp; ++i) {
+    if (!E[i].valid) continue;
+    if (ne < cap_edges) {
+      float* o = edges + (size_t)ne * 9;
+      for (int k = 0; k < 3; ++k) { o[k] = E[i].cp[k]; o[3 + k] = E[i].a[k]; o[6 + k] = E[i].b[k]; }
+      if (edge_query) edge_query[ne] = i;
+    }
+    ++ne;
+  }
+  for (int i = 0; i < m.n_flat; ++i) {
+    if (!P[i].valid) continue;
+    if (np < cap_planes) {
+      float* o = planes + (size_t)np * 12;
+      for (int k = 0; k < 3; ++k) { o[k] = P[i].cp[k]; o[3 + k] = P[i].j[k]; o[6 + k] = P[i].l[k]; o[9 + k] = P[i].m[k]; }
+      if (plane_query) plane_query[np] = i;
+    }
+    ++np;
+  }
+  *n_edges = ne;
+  *n_planes = np;
+  return ALOAM_OK;
+}
+
+// ---- profiling -----------------------------------------------------------------------------------------------
+int aloam_profile_enable(aloam_ctx* c, int on) {
+  if (!c) return ALOAM_E_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_resolve(c);
+  if (on) { for (int k = 0; k < K_COUNT; ++k) { c->prof_ms[k] = 0; c->prof_launches[k] = 0; } }
+  c->prof_on = on != 0;
+  return ALOAM_OK;
+}
+int aloam_profile_kernel_count(void) { return K_COUNT; }
+const char* aloam_profile_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
+
+int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* launches, double* algorithmic_bytes) {
+  if (!c || kernel < 0 || kernel >= K_COUNT) return ALOAM_E_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  prof_resolve(c);
+  if (total_ms) *total_ms = c->prof_ms[kernel];
+  if (launches) *launches = c->prof_launches[kernel];
+  if (algorithmic_bytes) {
+    // per-launch algorithmic traffic from the sizes of the LAST sweep (DESIGN.md "Algorithmic bytes")
+    std::vector<SeqMeta> m(c->B);
+    HIP_TRY(c, hipMemcpy(m.data(), c->d_meta, sizeof(SeqMeta) * c->B, hipMemcpyDeviceToHost));
+    double bytes = 0;
+    for (int b = 0; b < c->B; ++b) {
+      const double Nin = m[b].n_in, N = m[b].n_cloud, Fc = m[b].n_sharp, Lc = m[b].n_less_sharp, Fs = m[b].n_flat, Ls = m[b].n_less_flat;
+      const double Lcl = m[b].n_corner_last, Lsl = m[b].n_surf_last;
+      switch (kernel) {
+        case K_FIND_ENDS: bytes += 2 * 256 * 16; break;
+        case K_CLASSIFY: bytes += 16 * Nin + 5 * Nin; break;
+        case K_RING_OFFSETS: bytes += 8.0 * c->NB * c->R; break;
+        case K_SCATTER: bytes += 21 * Nin + 16 * N; break;
+        case K_RING_FEATURES: bytes += 16 * N + 5 * N + 16 * Ls; break;
+        case K_COMPACT: bytes += 32 * (Fc + Lc + Fs) + 32 * Ls; break;
+        case K_NN_CORNER: bytes += 16 * (Fc + Lcl) + 8 * Fc; break;
+        case K_NN_PLANE: bytes += 16 * (Fs + Lsl) + 8 * Fs; break;
+        case K_WALK_CORNER: bytes += 16 * (Fc + Lcl) + 48 * Fc; break;
+        case K_WALK_PLANE: bytes += 16 * (Fs + Lsl) + 64 * Fs; break;
+        case K_SOLVE: bytes += 9.0 * (48 * Fc + 64 * Fs); break;
+        default: break;
+      }
+    }
+    *algorithmic_bytes = bytes;
+  }
+  return ALOAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+// a-loam_amd/csrc/aloam_device.hpp — device-side layouts and helpers shared by the gfx950 kernels.
+//
+// Compiled with -ffp-contract=off: every decision quantity (range test, ring id, relative time, curvature,
+// gap test, voxel index, squared distances) is evaluated with the individually rounded IEEE operations the
+// reference's x86-64 build performs, in the same order, so discrete decisions match bit-for-bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace aloam {
+
+constexpr int kBlockPts = 1024;        // points per classify / scatter workgroup (256 threads x 4)
+constexpr int kMaxRings = 128;
+constexpr int kSectors = 6;            // reference src/scanRegistration.cpp:282
+constexpr int kSharpPerSector = 2;     // :301
+constexpr int kLessSharpPerSector = 20;// :307
+constexpr int kFlatPerSector = 4;      // :359
+constexpr int kNnTile = 1024;          // targets staged in LDS per NN workgroup
+
+enum ErrBits { kErrEmpty = 1, kErrRingCap = 2, kErrPointCap = 4 };
+
+struct alignas(16) SeqMeta {           // one per sequence, device resident
+  int n_in;
+  int first_kept, last_kept;
+  int half_idx;                        // index of the point that flips halfPassed (src/scanRegistration.cpp:220-223)
+  float start_ori, end_ori;            // :141-153
+  int n_cloud;
+  int err;
+  int n_sharp, n_less_sharp, n_flat, n_less_flat;   // current sweep
+  int n_corner_last, n_surf_last;                   // previous sweep (laserCloudCornerLast / SurfLast)
+  int pad0, pad1;
+};
+
+struct alignas(16) OdomState {         // one per sequence, device resident
+  double para_q[4];                    // src/laserOdometry.cpp:97  (x,y,z,w)
+  double para_t[3];                    // :98
+  double q_w[4];                       // :93       (x,y,z,w)
+  double t_w[3];                       // :94
+  int corner_corr[2], plane_corr[2];
+  int lm_iterations[2], lm_successful[2];
+  double initial_cost[2], final_cost[2];
+  int termination[2];
+  int pad[2];
+};
+
+struct EdgeRec { float cp[3], a[3], b[3]; int valid; int pad[2]; };          // 48 B : LidarEdgeFactor ctor args
+struct PlaneRec { float cp[3], j[3], l[3], m[3]; int valid; int pad[3]; };   // 64 B : LidarPlaneFactor ctor args
+
+// Everything the registration kernels need; passed by value.
+struct RegArgs {
+  const char* in;            // batch of input scans
+  long long seq_stride;      // bytes between sequences
+  int pt_stride;             // bytes between points
+  int B, cap, R, NB;         // batch, max_points, rings, blocks per scan
+  int ring_from_field;
+  float min_range;
+  SeqMeta* meta;             // [B]
+  int8_t* ringid;            // [B][cap]
+  float* ori;                // [B][cap] raw -atan2f(y,x)
+  int* hist;                 // [B][NB][R]
+  int* blockoff;             // [B][NB][R]
+  int* ringstart;            // [B][R+1]
+  float4* cloud;             // [B][cap] ring-ordered
+  float* curv;               // [B][cap]
+  int8_t* label;             // [B][cap]
+  int* sharp_idx;            // [B][R][6][2]   indices into cloud
+  int* less_sharp_idx;       // [B][R][6][20]
+  int* flat_idx;             // [B][R][6][4]
+  int* pick_cnt;             // [B][R][6][3]   (sharp, less_sharp, flat)
+  float4* lf_ring;           // [B][cap] per-ring voxel output, stored at the ring's offset
+  int* lf_cnt;               // [B][R]
+  float4* sharp;             // [B][R*12]
+  float4* less_sharp;        // [B][R*120]   (current buffer)
+  float4* flat;              // [B][R*24]
+  float4* less_flat;         // [B][cap]     (current buffer)
+};
+
+struct OdomArgs {
+  int B, cap, R;
+  SeqMeta* meta;
+  OdomState* state;
+  const float4* sharp;       // [B][R*12]
+  const float4* flat;        // [B][R*24]
+  const float4* corner_last; // [B][R*120]
+  const float4* surf_last;   // [B][cap]
+  unsigned long long* nn_corner;   // [B][R*12]
+  unsigned long long* nn_surf;     // [B][R*24]
+  EdgeRec* edges;            // [B][R*12]
+  PlaneRec* planes;          // [B][R*24]
+  int outer;                 // which outer iteration (0/1)
+  int last_outer;            // 1: integrate the pose after solving (src/laserOdometry.cpp:504-505)
+  int lm_max_iterations;
+};
+
+__device__ __forceinline__ float4 load_point(const char* base, long long i, int stride) {
+  const float* p = reinterpret_cast<const float*>(base + i * (long long)stride);
+  if ((stride & 15) == 0) return *reinterpret_cast<const float4*>(p);
+  return make_float4(p[0], p[1], p[2], p[3]);
+}
+
+// NaN removal + removeClosedPointCloud (reference src/scanRegistration.cpp:136-137, :99): f32 arithmetic.
+__device__ __forceinline__ bool point_kept(const float4& p, float thres) {
+  if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return false;
+  const float r2 = p.x * p.x + p.y * p.y + p.z * p.z;
+  return !(r2 < thres * thres);
+}
+
+// ---- atan2f, FDLIBM-style float algorithm: identical bits to glibc 2.35's atan2f, which is what
+// `atan2` resolves to at reference src/scanRegistration.cpp:141-142,208 (using std::atan2, :56). ----
+__device__ __forceinline__ float atanf_port(float x) {
+  const float hi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+  const float lo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+  const int hx = __float_as_int(x);
+  const int ix = hx & 0x7fffffff;
+  int id;
+  if (ix >= 0x4c000000) {
+    if (ix > 0x7f800000) return x + x;
+    return hx > 0 ? hi[3] + lo[3] : -hi[3] - lo[3];
+  }
+  if (ix < 0x3ee00000) {
+    if (ix < 0x31000000) return x;
+    id = -1;
+  } else {
+    x = fabsf(x);
+    if (ix < 0x3f980000) {
+      if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+      else                 { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+    } else {
+      if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+      else                 { id = 3; x = -1.0f / x; }
+    }
+  }
+  const float z = x * x;
+  const float w = z * z;
+  const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+  const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
+  if (id < 0) return x - x * (s1 + s2);
+  const float r = hi[id] - ((x * (s1 + s2) - lo[id]) - x);
+  return hx < 0 ? -r : r;
+}
+
+__device__ __forceinline__ float atan2f_port(float y, float x) {
+  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+  const int hx = __float_as_int(x), hy = __float_as_int(y);
+  const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+  if (hx == 0x3f800000) return atanf_port(y);
+  const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+  if (iy == 0) {
+    if (m < 2) return y;
+    return m == 2 ? pi + tiny : -pi - tiny;
+  }
+  if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  if (ix == 0x7f800000) {
+    if (iy == 0x7f800000) {
+      switch (m) { case 0: return pi_o_4 + tiny; case 1: return -pi_o_4 - tiny; case 2: return 3.0f * pi_o_4 + tiny; default: return -3.0f * pi_o_4 - tiny; }
+    }
+    switch (m) { case 0: return 0.0f; case 1: return -0.0f; case 2: return pi + tiny; default: return -pi - tiny; }
+  }
+  if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+  const int k = (iy - ix) >> 23;
+  float z;
+  if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+  else if (hx < 0 && k < -60) z = 0.0f;
+  else z = atanf_port(fabsf(y / x));
+  switch (m) {
+    case 0: return z;
+    case 1: return __int_as_float(__float_as_int(z) ^ (int)0x80000000);
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+  }
+}
+
+// 64-bit wave shuffles
+__device__ __forceinline__ double shfl_down_f64(double v, int d) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_down(lo, d, 64);
+  hi = __shfl_down(hi, d, 64);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = __shfl_xor(lo, m, 64);
+  hi = __shfl_xor(hi, m, 64);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+}  // namespace aloam

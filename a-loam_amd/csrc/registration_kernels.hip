@@ -1,0 +1,576 @@
+// a-loam_amd/csrc/registration_kernels.hip — gfx950 kernels for A-LOAM scan registration.
+//
+// Replaces the body of laserCloudHandler (reference src/scanRegistration.cpp:127-411) for a BATCH of
+// independent sweeps.  Kernel <-> reference map:
+//   k_find_ends       :136-153   first / last kept point, startOri / endOri
+//   k_classify        :85-112,160-236  NaN + range filter, ring id, raw azimuth, halfPassed flip index,
+//                                per-block ring histograms
+//   k_ring_offsets    :246-252   ring start offsets (exclusive scans of the histograms)
+//   k_scatter         :208-241   relTime -> intensity, STABLE per-ring compaction into the ring-ordered cloud
+//   k_ring_features   :256-407   one workgroup per (sweep, ring): 11-tap curvature from an LDS tile, 6-sector
+//                                sort (LDS bitonic), greedy corner / flat picking with neighbour suppression,
+//                                less-flat gather + 0.2 m voxel centroids (pcl::VoxelGrid stand-in)
+//   k_compact_features :304-310,356,407  append per-(ring,sector) picks in the reference's output order
+//
+// All of it is HBM/latency-bound integer + f32 work: coalesced 16-B loads, LDS staging, wave64 ballots; no MFMA.
+#include "aloam_device.hpp"
+#include "registration_kernels.hpp"
+
+namespace aloam {
+
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_find_ends(RegArgs a, const int* __restrict__ n_in) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = n_in[b];
+  const char* in = a.in + (long long)b * a.seq_stride;
+  __shared__ int s_first, s_last;
+  if (tid == 0) { s_first = 0x7fffffff; s_last = -1; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + tid;
+    const bool k = i < n && point_kept(load_point(in, i, a.pt_stride), a.min_range);
+    if (k) atomicMin(&s_first, i);
+    if (__syncthreads_or(k)) break;
+  }
+  for (int base = 0; base < n; base += 256) {
+    const int i = n - 1 - (base + tid);
+    const bool k = i >= 0 && point_kept(load_point(in, i, a.pt_stride), a.min_range);
+    if (k) atomicMax(&s_last, i);
+    if (__syncthreads_or(k)) break;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    SeqMeta m = a.meta[b];
+    m.n_in = n;
+    m.first_kept = s_first;
+    m.last_kept = s_last;
+    m.half_idx = 0x7fffffff;
+    m.err = 0;
+    m.n_cloud = 0;
+    m.start_ori = 0.f;
+    m.end_ori = 0.f;
+    if (s_last < 0) {
+      m.err = kErrEmpty;
+    } else {
+      const float4 p0 = load_point(in, s_first, a.pt_stride);
+      const float4 p1 = load_point(in, s_last, a.pt_stride);
+      const float startOri = -atan2f_port(p0.y, p0.x);                                  // :141
+      float endOri = (float)((double)(-atan2f_port(p1.y, p1.x)) + 2 * M_PI);             // :142-144
+      if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);      // :146-149
+      else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);     // :150-153
+      m.start_ori = startOri;
+      m.end_ori = endOri;
+    }
+    if (n > a.cap) m.err |= kErrPointCap;
+    a.meta[b] = m;
+  }
+}
+
+// Ring id of a kept point (reference src/scanRegistration.cpp:166-205); -1 = rejected.
+__device__ __forceinline__ int ring_of(const float4& p, int R, int ring_from_field) {
+  int scanID;
+  if (ring_from_field) {
+    scanID = (int)p.w;
+    return (scanID > R - 1 || scanID < 0) ? -1 : scanID;
+  }
+  // `atan` / `sqrt` unqualified at :166 -> double overloads on the pinned toolchain; sqrt's argument is an f32 sum.
+  const float angle = (float)(atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI);
+  if (R == 16) {
+    scanID = (int)((double)((angle + 15) / 2) + 0.5);
+    return (scanID > R - 1 || scanID < 0) ? -1 : scanID;
+  }
+  if (R == 32) {
+    scanID = (int)(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);
+    return (scanID > R - 1 || scanID < 0) ? -1 : scanID;
+  }
+  if ((double)angle >= -8.83) scanID = (int)((double)(2 - angle) * 3.0 + 0.5);
+  else scanID = R / 2 + (int)((-8.83 - (double)angle) * 2.0 + 0.5);
+  if ((double)angle > 2 || (double)angle < -24.33 || scanID > 50 || scanID < 0) return -1;
+  return scanID;
+}
+
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_classify(RegArgs a) {
+  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const SeqMeta m = a.meta[b];
+  const int n = m.n_in < a.cap ? m.n_in : a.cap;
+  if (blk * kBlockPts >= n && blk > 0) {      // still publish an empty histogram
+    for (int r = tid; r < a.R; r += 256) a.hist[((long long)b * a.NB + blk) * a.R + r] = 0;
+    return;
+  }
+  const char* in = a.in + (long long)b * a.seq_stride;
+  __shared__ int s_hist[kMaxRings];
+  __shared__ int s_half;
+  if (tid < kMaxRings) s_hist[tid] = 0;
+  if (tid == 0) s_half = 0x7fffffff;
+  __syncthreads();
+  const float startOri = m.start_ori;
+  int myhalf = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = blk * kBlockPts + k * 256 + tid;
+    int ring = -1;
+    float ori = 0.f;
+    if (i < n) {
+      const float4 p = load_point(in, i, a.pt_stride);
+      if (point_kept(p, a.min_range)) {
+        ring = ring_of(p, a.R, a.ring_from_field);
+        if (ring >= 0) {
+          ori = -atan2f_port(p.y, p.x);                                                     // :208
+          float o1 = ori;                                                                   // branch taken while !halfPassed
+          if ((double)o1 < (double)startOri - M_PI / 2) o1 = (float)((double)o1 + 2 * M_PI);          // :211-214
+          else if ((double)o1 > (double)startOri + M_PI * 3 / 2) o1 = (float)((double)o1 - 2 * M_PI); // :215-218
+          if ((double)(o1 - startOri) > M_PI && i < myhalf) myhalf = i;                      // :220-223
+        }
+      }
+      a.ringid[(long long)b * a.cap + i] = (int8_t)ring;
+      a.ori[(long long)b * a.cap + i] = ori;
+    }
+    // wave-aggregated histogram update: one LDS atomic per distinct ring in the wave
+    unsigned long long todo = __ballot(ring >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int r = __shfl(ring, leader, 64);
+      const unsigned long long same = __ballot(ring == r);
+      if (lane == leader) atomicAdd(&s_hist[r], __popcll(same));
+      todo &= ~same;
+    }
+  }
+  // block-wide min of the halfPassed flip index
+  for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_down(myhalf, d, 64); myhalf = o < myhalf ? o : myhalf; }
+  if (lane == 0 && myhalf != 0x7fffffff) atomicMin(&s_half, myhalf);
+  __syncthreads();
+  if (tid == 0 && s_half != 0x7fffffff) atomicMin(&a.meta[b].half_idx, s_half);
+  for (int r = tid; r < a.R; r += 256) a.hist[((long long)b * a.NB + blk) * a.R + r] = s_hist[r];
+}
+
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_ring_offsets(RegArgs a) {
+  const int b = blockIdx.x, r = threadIdx.x;
+  __shared__ int s_cnt[kMaxRings];
+  const int n = a.meta[b].n_in < a.cap ? a.meta[b].n_in : a.cap;
+  const int nb = (n + kBlockPts - 1) / kBlockPts;
+  if (r < a.R) {
+    int run = 0;
+    for (int blk = 0; blk < nb; ++blk) {
+      const long long o = ((long long)b * a.NB + blk) * a.R + r;
+      const int h = a.hist[o];
+      a.blockoff[o] = run;
+      run += h;
+    }
+    s_cnt[r] = run;
+  }
+  __syncthreads();
+  if (r == 0) {
+    int run = 0;
+    for (int q = 0; q < a.R; ++q) { a.ringstart[b * (a.R + 1) + q] = run; run += s_cnt[q]; }
+    a.ringstart[b * (a.R + 1) + a.R] = run;
+    a.meta[b].n_cloud = run;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
+  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const SeqMeta m = a.meta[b];
+  const int n = m.n_in < a.cap ? m.n_in : a.cap;
+  if (blk * kBlockPts >= n) return;
+  const char* in = a.in + (long long)b * a.seq_stride;
+  __shared__ int s_base[kMaxRings];
+  __shared__ int s_wcnt[4][kMaxRings];
+  if (tid < a.R) s_base[tid] = a.ringstart[b * (a.R + 1) + tid] + a.blockoff[((long long)b * a.NB + blk) * a.R + tid];
+  for (int q = tid; q < 4 * kMaxRings; q += 256) (&s_wcnt[0][0])[q] = 0;
+  __syncthreads();
+  const float startOri = m.start_ori, endOri = m.end_ori;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const int i = blk * kBlockPts + k * 256 + tid;
+    const int ring = (i < n) ? (int)a.ringid[(long long)b * a.cap + i] : -1;
+    // rank among the same-ring lanes of this wave (stable: lower lane = earlier point)
+    int rank = 0;
+    unsigned long long todo = __ballot(ring >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int r = __shfl(ring, leader, 64);
+      const unsigned long long same = __ballot(ring == r);
+      if (ring == r) rank = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) s_wcnt[wave][r] = __popcll(same);
+      todo &= ~same;
+    }
+    __syncthreads();
+    if (ring >= 0) {
+      int pos = s_base[ring] + rank;
+      for (int w = 0; w < wave; ++w) pos += s_wcnt[w][ring];
+      const float4 p = load_point(in, i, a.pt_stride);
+      float ori = a.ori[(long long)b * a.cap + i];
+      if (i <= m.half_idx) {                                                                    // !halfPassed when visited
+        if ((double)ori < (double)startOri - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
+        else if ((double)ori > (double)startOri + M_PI * 3 / 2) ori = (float)((double)ori - 2 * M_PI);
+      } else {                                                                                  // :225-236
+        ori = (float)((double)ori + 2 * M_PI);
+        if ((double)ori < (double)endOri - M_PI * 3 / 2) ori = (float)((double)ori + 2 * M_PI);
+        else if ((double)ori > (double)endOri + M_PI / 2) ori = (float)((double)ori - 2 * M_PI);
+      }
+      const float relTime = (ori - startOri) / (endOri - startOri);                             // :238
+      const float inten = (float)((double)ring + 0.1 * (double)relTime);                        // :239, scanPeriod 0.1
+      a.cloud[(long long)b * a.cap + pos] = make_float4(p.x, p.y, p.z, inten);
+    }
+    __syncthreads();
+    if (tid < a.R) {
+      int add = 0;
+      for (int w = 0; w < 4; ++w) { add += s_wcnt[w][tid]; s_wcnt[w][tid] = 0; }
+      s_base[tid] += add;
+    }
+    __syncthreads();
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+// LDS bitonic sort of npad (power of two) 64-bit keys, ascending, 256 threads.
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int npad, int tid) {
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += 256) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i + j;
+        const unsigned long long x = keys[i], y = keys[l];
+        const bool up = (i & k) == 0;
+        if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// Neighbour suppression after a pick (reference src/scanRegistration.cpp:317-342 / :364-388).  flags bit0 = picked,
+// bit1 = "squared gap between point i and i+1 exceeds 0.05".  Executed by one wave; lanes 0..10 act.
+__device__ __forceinline__ void suppress_neighbours(volatile unsigned char* flags, int kf, int lane) {
+  bool g = false;
+  if (lane >= 1 && lane <= 5) g = (flags[kf + lane - 1] & 2) != 0;        // step (kf+l-1 -> kf+l), l = lane
+  else if (lane >= 6 && lane <= 10) g = (flags[kf - (lane - 5)] & 2) != 0; // step (kf-m -> kf-m+1), m = lane-5
+  const unsigned long long gb = __ballot(g);
+  const unsigned fwd = (unsigned)(gb >> 1) & 31u, bwd = (unsigned)(gb >> 6) & 31u;
+  const int nf = fwd ? (__ffs((int)fwd) - 1) : 5;      // number of forward neighbours marked
+  const int nb = bwd ? (__ffs((int)bwd) - 1) : 5;
+  if (lane == 0) flags[kf] = flags[kf] | 1;
+  else if (lane >= 1 && lane <= 5) { if (lane - 1 < nf) flags[kf + lane] = flags[kf + lane] | 1; }
+  else if (lane >= 6 && lane <= 10) { if (lane - 6 < nb) flags[kf - (lane - 5)] = flags[kf - (lane - 5)] | 1; }
+}
+
+template <int NPAD>
+__global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
+  constexpr int MAXN = NPAD + 11;
+  constexpr int ITEMS = (MAXN + 255) / 256;
+  const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int start = a.ringstart[b * (a.R + 1) + r];
+  const int n = a.ringstart[b * (a.R + 1) + r + 1] - start;
+  int* pick_cnt = a.pick_cnt + ((long long)(b * a.R + r) * kSectors) * 3;
+  if (tid < kSectors * 3) pick_cnt[tid] = 0;
+  if (tid == 0) a.lf_cnt[b * a.R + r] = 0;
+  if (n - 11 < 6) return;                                                   // :279
+  if (n > MAXN) { if (tid == 0) atomicOr(&a.meta[b].err, kErrRingCap); return; }
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // region A: SoA xyz tile during the curvature pass, then the sort keys (aliased)
+  constexpr int A_BYTES = (12 * MAXN > 8 * NPAD ? 12 * MAXN : 8 * NPAD);
+  float* xs = reinterpret_cast<float*>(smem);
+  float* ys = xs + MAXN;
+  float* zs = ys + MAXN;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  // all scratch lives in the dynamic region so its base stays 16-byte aligned (no static __shared__ in front)
+  constexpr int FLAG_BYTES = (MAXN + 15) & ~15;
+  volatile unsigned char* flags = smem + ((A_BYTES + 15) & ~15);
+  volatile signed char* label = reinterpret_cast<volatile signed char*>(flags + FLAG_BYTES);
+  int* s_scan = reinterpret_cast<int*>(smem + ((A_BYTES + 15) & ~15) + 2 * FLAG_BYTES);
+  float (*s_red)[4] = reinterpret_cast<float (*)[4]>(s_scan + 256);
+  int* s_misc = reinterpret_cast<int*>(s_scan + 256 + 24);
+
+  const float4* cloud = a.cloud + (long long)b * a.cap + start;
+  for (int i = tid; i < n; i += 256) {
+    const float4 p = cloud[i];
+    xs[i] = p.x; ys[i] = p.y; zs[i] = p.z;
+  }
+  __syncthreads();
+
+  // ---- curvature (:256-266) + gap flags, kept in registers until the tile is retired
+  const int L = n - 11;                          // E - S
+  float cv[ITEMS];
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int i = tid + it * 256;
+    cv[it] = 0.f;
+    if (i < n) {
+      unsigned char f = 0;
+      if (i < n - 1) {
+        const float dx = xs[i + 1] - xs[i], dy = ys[i + 1] - ys[i], dz = zs[i + 1] - zs[i];
+        if ((double)(dx * dx + dy * dy + dz * dz) > 0.05) f = 2;              // :324 etc.
+      }
+      if (i >= 5 && i < n - 5) {
+        const float dX = xs[i - 5] + xs[i - 4] + xs[i - 3] + xs[i - 2] + xs[i - 1] - 10 * xs[i] + xs[i + 1] + xs[i + 2] + xs[i + 3] + xs[i + 4] + xs[i + 5];
+        const float dY = ys[i - 5] + ys[i - 4] + ys[i - 3] + ys[i - 2] + ys[i - 1] - 10 * ys[i] + ys[i + 1] + ys[i + 2] + ys[i + 3] + ys[i + 4] + ys[i + 5];
+        const float dZ = zs[i - 5] + zs[i - 4] + zs[i - 3] + zs[i - 2] + zs[i - 1] - 10 * zs[i] + zs[i + 1] + zs[i + 2] + zs[i + 3] + zs[i + 4] + zs[i + 5];
+        cv[it] = dX * dX + dY * dY + dZ * dZ;
+        a.curv[(long long)b * a.cap + start + i] = cv[it];
+      }
+      flags[i] = f;
+      label[i] = 0;
+    }
+  }
+  __syncthreads();
+
+  // ---- sort keys: (sector, curvature bits, local index); selectable points are local 5 .. n-7 (:249-251,284-285)
+  const int npad = pow2ceil(L);
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int i = tid + it * 256;
+    const int e = i - 5;
+    if (e >= 0 && e < L) {
+      int sec = 5;
+      while (sec > 0 && (L * sec) / 6 > e) --sec;
+      keys[e] = ((unsigned long long)sec << 48) | ((unsigned long long)__float_as_uint(cv[it]) << 16) | (unsigned long long)i;
+    }
+  }
+  for (int e = L + tid; e < npad; e += 256) keys[e] = ~0ull;
+  __syncthreads();
+  bitonic_sort_u64(keys, npad, tid);
+
+  // ---- greedy picking, sectors in order (suppression marks spill across sector borders) — one wave
+  if (wave == 0) {
+    int* sharp_idx = a.sharp_idx + ((long long)(b * a.R + r) * kSectors) * kSharpPerSector;
+    int* less_idx = a.less_sharp_idx + ((long long)(b * a.R + r) * kSectors) * kLessSharpPerSector;
+    int* flat_idx = a.flat_idx + ((long long)(b * a.R + r) * kSectors) * kFlatPerSector;
+    for (int j = 0; j < kSectors; ++j) {
+      const int sp = (L * j) / 6, ep = (L * (j + 1)) / 6 - 1;
+      // corners: largest curvature first (:291-344)
+      int count = 0;
+      bool done = false;
+      for (int base = ep; base >= sp && !done; base -= 64) {
+        const int pos = base - lane;
+        const bool valid = pos >= sp;
+        const unsigned long long key = valid ? keys[pos] : 0ull;
+        const int kpt = (int)(key & 0xffffull);
+        const float c = __uint_as_float((unsigned)((key >> 16) & 0xffffffffull));
+        bool cand = valid && ((double)c > 0.1);
+        while (true) {
+          const bool ok = cand && !(flags[kpt] & 1);
+          const unsigned long long mask = __ballot(ok);
+          if (!mask) break;
+          const int f = __ffsll((long long)mask) - 1;
+          const int kf = __shfl(kpt, f, 64);
+          ++count;
+          if (count > kLessSharpPerSector) { done = true; break; }           // 21st: break before marking (:312-315)
+          if (lane == 0) {
+            label[kf] = count <= kSharpPerSector ? 2 : 1;
+            if (count <= kSharpPerSector) sharp_idx[j * kSharpPerSector + count - 1] = start + kf;
+            less_idx[j * kLessSharpPerSector + count - 1] = start + kf;
+          }
+          suppress_neighbours(flags, kf, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          cand = cand && lane > f;
+        }
+      }
+      const int ncorner = count > kLessSharpPerSector ? kLessSharpPerSector : count;
+      // flats: smallest curvature first (:346-390)
+      count = 0;
+      done = false;
+      for (int base = sp; base <= ep && !done; base += 64) {
+        const int pos = base + lane;
+        const bool valid = pos <= ep;
+        const unsigned long long key = valid ? keys[pos] : 0ull;
+        const int kpt = (int)(key & 0xffffull);
+        const float c = __uint_as_float((unsigned)((key >> 16) & 0xffffffffull));
+        bool cand = valid && ((double)c < 0.1);
+        while (true) {
+          const bool ok = cand && !(flags[kpt] & 1);
+          const unsigned long long mask = __ballot(ok);
+          if (!mask) break;
+          const int f = __ffsll((long long)mask) - 1;
+          const int kf = __shfl(kpt, f, 64);
+          if (lane == 0) { label[kf] = -1; flat_idx[j * kFlatPerSector + count] = start + kf; }
+          ++count;
+          if (count >= kFlatPerSector) { done = true; break; }                // 4th: break before marking (:359-362)
+          suppress_neighbours(flags, kf, lane);
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          cand = cand && lane > f;
+        }
+      }
+      if (lane == 0) {
+        pick_cnt[j * 3 + 0] = ncorner < kSharpPerSector ? ncorner : kSharpPerSector;
+        pick_cnt[j * 3 + 1] = ncorner;
+        pick_cnt[j * 3 + 2] = count;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- labels out (parity / debugging) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
+  for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
+
+  // ---- pcl::VoxelGrid (leaf 0.2) over the less-flat points of this ring (:401-405)
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int e = tid; e < L; e += 256) {
+    const int i = e + 5;
+    if (label[i] <= 0) {
+      const float4 p = cloud[i];
+      mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+      mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+      mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    for (int d = 32; d > 0; d >>= 1) { mn[q] = fminf(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = fmaxf(mx[q], __shfl_down(mx[q], d, 64)); }
+    if (lane == 0) { s_red[q][wave] = mn[q]; s_red[3 + q][wave] = mx[q]; }
+  }
+  __syncthreads();
+  const float inv = 1.0f / leaf;
+  int minb[3], divb[3];
+  float fminb[3];
+  bool overflow;
+  {
+    float gmn[3], gmx[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      gmn[q] = fminf(fminf(s_red[q][0], s_red[q][1]), fminf(s_red[q][2], s_red[q][3]));
+      gmx[q] = fmaxf(fmaxf(s_red[3 + q][0], s_red[3 + q][1]), fmaxf(s_red[3 + q][2], s_red[3 + q][3]));
+    }
+    const long long dx = (long long)((gmx[0] - gmn[0]) * inv) + 1, dy = (long long)((gmx[1] - gmn[1]) * inv) + 1, dz = (long long)((gmx[2] - gmn[2]) * inv) + 1;
+    overflow = dx * dy * dz > 2147483647ll;   // PCL returns the input unfiltered in this case
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      minb[q] = (int)floorf(gmn[q] * inv);
+      divb[q] = (int)floorf(gmx[q] * inv) - minb[q] + 1;
+      fminb[q] = (float)minb[q];
+    }
+  }
+  for (int e = tid; e < npad; e += 256) {
+    unsigned long long key = ~0ull;
+    const int i = e + 5;
+    if (e < L && label[i] <= 0) {
+      const float4 p = cloud[i];
+      unsigned vi;
+      if (overflow) vi = (unsigned)e;         // every point its own cell -> output = input, in order
+      else {
+        const int i0 = (int)(floorf(p.x * inv) - fminb[0]);
+        const int i1 = (int)(floorf(p.y * inv) - fminb[1]);
+        const int i2 = (int)(floorf(p.z * inv) - fminb[2]);
+        vi = (unsigned)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]);
+      }
+      key = ((unsigned long long)vi << 32) | (unsigned long long)i;
+    }
+    keys[e] = key;
+  }
+  __syncthreads();
+  bitonic_sort_u64(keys, npad, tid);
+
+  // segment heads -> output rank (ascending voxel index), centroid = f32 sums in input order / count
+  const int chunk = npad / 256 > 0 ? npad / 256 : 1;
+  const int p0 = tid * chunk, p1 = (p0 + chunk < npad) ? p0 + chunk : npad;
+  int heads = 0;
+  for (int p = p0; p < p1 && p < npad; ++p) {
+    const unsigned long long key = keys[p];
+    if (key == ~0ull) break;
+    if (p == 0 || (unsigned)(keys[p - 1] >> 32) != (unsigned)(key >> 32)) ++heads;
+  }
+  if (tid * chunk >= npad) heads = 0;
+  s_scan[tid] = heads;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = tid >= d ? s_scan[tid - d] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  int rank = s_scan[tid] - heads;
+  if (tid == 255) s_misc[0] = s_scan[255];
+  float4* out = a.lf_ring + (long long)b * a.cap + start;
+  for (int p = p0; p < p1 && p < npad; ++p) {
+    const unsigned long long key = keys[p];
+    if (key == ~0ull) break;
+    const unsigned vi = (unsigned)(key >> 32);
+    if (p == 0 || (unsigned)(keys[p - 1] >> 32) != vi) {
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+      int cnt = 0;
+      for (int q = p; q < npad; ++q) {
+        const unsigned long long kq = keys[q];
+        if ((unsigned)(kq >> 32) != vi || kq == ~0ull) break;
+        const float4 pt = cloud[(int)(kq & 0xffffffffull)];
+        sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
+        ++cnt;
+      }
+      const float fc = (float)cnt;
+      out[rank++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) a.lf_cnt[b * a.R + r] = s_misc[0];
+}
+
+// -------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compact_features(RegArgs a) {
+  const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  __shared__ int s_base[4];          // sharp, less_sharp, flat, less_flat offsets of this ring
+  __shared__ int s_own[4];
+  const int* pc = a.pick_cnt + (long long)b * a.R * kSectors * 3;
+  const int* lc = a.lf_cnt + b * a.R;
+  if (tid < 4) { s_base[tid] = 0; s_own[tid] = 0; }
+  __syncthreads();
+  int acc[4] = {0, 0, 0, 0}, own[4] = {0, 0, 0, 0};
+  for (int q = tid; q < (r + 1) * kSectors; q += 256) {
+    const int rr = q / kSectors;
+    for (int c = 0; c < 3; ++c) { const int v = pc[q * 3 + c]; if (rr < r) acc[c] += v; else own[c] += v; }
+  }
+  for (int q = tid; q <= r; q += 256) { if (q < r) acc[3] += lc[q]; else own[3] += lc[q]; }
+  for (int c = 0; c < 4; ++c) { if (acc[c]) atomicAdd(&s_base[c], acc[c]); if (own[c]) atomicAdd(&s_own[c], own[c]); }
+  __syncthreads();
+  const float4* cloud = a.cloud + (long long)b * a.cap;
+  const int nslot[3] = {kSharpPerSector, kLessSharpPerSector, kFlatPerSector};
+  const int* idx[3] = {a.sharp_idx + (long long)(b * a.R + r) * kSectors * kSharpPerSector,
+                       a.less_sharp_idx + (long long)(b * a.R + r) * kSectors * kLessSharpPerSector,
+                       a.flat_idx + (long long)(b * a.R + r) * kSectors * kFlatPerSector};
+  float4* dst[3] = {a.sharp + (long long)b * a.R * 12, a.less_sharp + (long long)b * a.R * 120, a.flat + (long long)b * a.R * 24};
+  constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;   // 26 pick slots per sector
+  if (tid < kSectors * kSlots) {
+    const int j = tid / kSlots, slot = tid % kSlots;
+    const int c = slot < kSharpPerSector ? 0 : (slot < kSharpPerSector + kLessSharpPerSector ? 1 : 2);
+    const int sidx = slot - (c == 0 ? 0 : (c == 1 ? kSharpPerSector : kSharpPerSector + kLessSharpPerSector));
+    if (sidx < pc[(r * kSectors + j) * 3 + c]) {
+      int o = s_base[c] + sidx;
+      for (int jj = 0; jj < j; ++jj) o += pc[(r * kSectors + jj) * 3 + c];
+      dst[c][o] = cloud[idx[c][j * nslot[c] + sidx]];
+    }
+  }
+  const int start = a.ringstart[b * (a.R + 1) + r];
+  const float4* src = a.lf_ring + (long long)b * a.cap + start;
+  float4* lf = a.less_flat + (long long)b * a.cap + s_base[3];
+  for (int q = tid; q < s_own[3]; q += 256) lf[q] = src[q];
+  if (r == a.R - 1 && tid == 0) {
+    a.meta[b].n_sharp = s_base[0] + s_own[0];
+    a.meta[b].n_less_sharp = s_base[1] + s_own[1];
+    a.meta[b].n_flat = s_base[2] + s_own[2];
+    a.meta[b].n_less_flat = s_base[3] + s_own[3];
+  }
+}
+
+// -------------------------------------------------------------------------------------------------------
+size_t ring_features_lds_bytes(int npad) {
+  const int maxn = npad + 11;
+  const int a_bytes = (12 * maxn > 8 * npad ? 12 * maxn : 8 * npad);
+  const int flag_bytes = (maxn + 15) & ~15;
+  return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 4) * sizeof(int);
+}
+
+void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s) { hipLaunchKernelGGL(k_find_ends, dim3(a.B), dim3(256), 0, s, a, d_nin); }
+void launch_classify(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_classify, dim3(a.NB, a.B), dim3(256), 0, s, a); }
+void launch_ring_offsets(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ring_offsets, dim3(a.B), dim3(128), 0, s, a); }
+void launch_scatter(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_scatter, dim3(a.NB, a.B), dim3(256), 0, s, a); }
+void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s) {
+  const size_t lds = ring_features_lds_bytes(npad);
+  if (npad <= 2048) hipLaunchKernelGGL(k_ring_features<2048>, dim3(a.R, a.B), dim3(256), lds, s, a, leaf);
+  else hipLaunchKernelGGL(k_ring_features<4096>, dim3(a.R, a.B), dim3(256), lds, s, a, leaf);
+}
+void launch_compact_features(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_compact_features, dim3(a.R, a.B), dim3(256), 0, s, a); }
+
+}  // namespace aloam

@@ -1,0 +1,127 @@
+/* include/aloam_mi355x.h — C ABI of libaloam_mi355x.so: the MI355X (gfx950) drop-in for A-LOAM's hot path.
+ *
+ * The reference (HKUST-Aerial-Robotics/A-LOAM) has no plugin / FFI interface: each stage is a ROS node whose
+ * per-scan work sits in one function body over file-scope globals.  This ABI cuts exactly at those bodies
+ * (SURVEY.md §8(b) "B2 in-process function seams"); every entry point below names the reference code it
+ * replaces.  A ROS node keeps its subscribe / sync / publish code and calls these instead of PCL + Ceres
+ * (INTEGRATION.md shows the ~50-line change per node).
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary; return 0 = ok, negative = error (aloam_last_error()).
+ *   - one aloam_ctx = `batch` independent sequences advanced in lock-step on ONE device and ONE HIP stream
+ *     (batch = 1 is the reference's single-sensor node).  A context is not thread-safe; distinct contexts
+ *     are independent (one per GPU / per process for multi-GPU; no collectives — sequences never exchange data).
+ *   - points are 16-byte records {float x, y, z, w}; w = `intensity` of pcl::PointXYZI
+ *     (reference include/aloam_velodyne/common.h:43).  Input records may use any stride >= 16 bytes
+ *     (32 = the PointCloud2 point_step pcl::toROSMsg<PointXYZI> produces, reference src/kittiHelper.cpp:153-154).
+ *   - quaternions are (x, y, z, w) like para_q (reference src/laserOdometry.cpp:96-100).
+ *   - there is NO CPU fallback: every entry point fails with ALOAM_E_HIP if the HIP runtime / a gfx950 device
+ *     is unavailable.
+ */
+#ifndef ALOAM_MI355X_H_
+#define ALOAM_MI355X_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct aloam_ctx aloam_ctx;
+
+enum {
+  ALOAM_OK = 0,
+  ALOAM_E_ARG = -1,        /* bad argument */
+  ALOAM_E_SCAN_LINES = -2, /* n_scans not 16/32/64 without ring_from_field (reference src/scanRegistration.cpp:472-476) */
+  ALOAM_E_EMPTY = -3,      /* no point of some scan survives the NaN / minimum-range filter */
+  ALOAM_E_CAPACITY = -4,   /* a scan exceeds max_points or a ring exceeds max_ring_points */
+  ALOAM_E_HIP = -5,        /* HIP runtime error / no device */
+  ALOAM_E_STATE = -6       /* call order (e.g. odometry before any registration) */
+};
+
+/* Launch-file parameters (reference launch/aloam_velodyne_HDL_64.launch:3-13) + sizing of the device buffers. */
+typedef struct aloam_config {
+  int n_scans;             /* `scan_line`   : 16 / 32 / 64 (reference src/scanRegistration.cpp:466)                       */
+  float min_range;         /* `minimum_range` (reference src/scanRegistration.cpp:468): 0.3 VLP-16/HDL-32, 5 HDL-64          */
+  int ring_from_field;     /* 0: ring from the elevation formulas (src/scanRegistration.cpp:166-205); 1: ring = int(w)     */
+  int batch;               /* independent sequences processed per call                                                      */
+  int max_points;          /* capacity per scan; the reference's global arrays hold 400000 (src/scanRegistration.cpp:66-69) */
+  int max_ring_points;     /* capacity per ring: 2059 or 4107 (LDS sizing of the per-ring selection kernel)                 */
+  int device;              /* HIP device ordinal                                                                            */
+  int lm_max_iterations;   /* options.max_num_iterations = 4 (reference src/laserOdometry.cpp:496)                          */
+  int outer_iterations;    /* opti_counter loop = 2 (reference src/laserOdometry.cpp:278)                                   */
+} aloam_config;
+
+/* Which cloud of a sequence (topic names of reference src/scanRegistration.cpp:480-488, src/laserOdometry.cpp:205-209). */
+enum {
+  ALOAM_CLOUD_FULL = 0,        /* /velodyne_cloud_2        ring-ordered laserCloud                 */
+  ALOAM_CLOUD_SHARP = 1,       /* /laser_cloud_sharp                                              */
+  ALOAM_CLOUD_LESS_SHARP = 2,  /* /laser_cloud_less_sharp                                         */
+  ALOAM_CLOUD_FLAT = 3,        /* /laser_cloud_flat                                               */
+  ALOAM_CLOUD_LESS_FLAT = 4,   /* /laser_cloud_less_flat                                          */
+  ALOAM_CLOUD_CORNER_LAST = 5, /* /laser_cloud_corner_last (laserCloudCornerLast after the swap)  */
+  ALOAM_CLOUD_SURF_LAST = 6    /* /laser_cloud_surf_last   (laserCloudSurfLast after the swap)    */
+};
+
+typedef struct aloam_odom_stats {
+  int corner_corr[2];      /* corner_correspondence per outer iteration (reference src/laserOdometry.cpp:382) */
+  int plane_corr[2];       /* plane_correspondence  per outer iteration (reference src/laserOdometry.cpp:480) */
+  int lm_iterations[2];    /* LM iterations executed per ceres::Solve stand-in                                 */
+  int lm_successful[2];
+  double initial_cost[2];
+  double final_cost[2];
+  int termination[2];      /* 0 max-iter, 1 parameter tol, 2 function tol, 3 gradient tol, 4 no residuals, 5 failure */
+} aloam_odom_stats;
+
+/* ---- lifetime -------------------------------------------------------------------------------------------- */
+void aloam_default_config(aloam_config* cfg);                       /* HDL-64 launch values, batch 1           */
+int aloam_create(const aloam_config* cfg, aloam_ctx** out);          /* replaces the nodes' global state (src/scanRegistration.cpp:60-83, src/laserOdometry.cpp:59-108) */
+void aloam_destroy(aloam_ctx* ctx);
+const char* aloam_last_error(const aloam_ctx* ctx);                  /* replaces printf / ROS_BREAK diagnostics */
+void* aloam_stream(aloam_ctx* ctx);                                  /* the hipStream_t all work is queued on   */
+int aloam_synchronize(aloam_ctx* ctx);                               /* waits + surfaces device-side error flags */
+
+/* ---- stage 1: body of laserCloudHandler (reference src/scanRegistration.cpp:127-411) ----------------------- */
+/* Host input: scans[b] points to n_in[b] records of stride_bytes.  Blocking w.r.t. the host buffers only.    */
+int aloam_scan_register(aloam_ctx* ctx, const void* const* scans, const int* n_in, int stride_bytes);
+/* Device-resident input: sequence b starts at d_scans + b * seq_stride_bytes.  Fully asynchronous.           */
+int aloam_scan_register_device(aloam_ctx* ctx, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes);
+
+/* ---- stage 2: odometry main-loop body (reference src/laserOdometry.cpp:265-506,554-568) -------------------- */
+int aloam_odometry_step(aloam_ctx* ctx);                             /* asynchronous; all sequences             */
+
+/* ---- throughput entry: stage 1 + stage 2 for one sweep of every sequence, asynchronous -------------------- */
+int aloam_process_device(aloam_ctx* ctx, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes);
+
+/* ---- results (each synchronises the stream) ---------------------------------------------------------------- */
+int aloam_cloud_size(aloam_ctx* ctx, int seq, int which);            /* replaces cloud.points.size()            */
+int aloam_get_cloud(aloam_ctx* ctx, int seq, int which, float* out_xyzw, int cap_points);  /* what pcl::toROSMsg publishes (src/scanRegistration.cpp:413-441, src/laserOdometry.cpp:574-590) */
+int aloam_get_pose(aloam_ctx* ctx, int seq, double q_w_curr[4], double t_w_curr[3], double q_last_curr[4], double t_last_curr[3]); /* /laser_odom_to_init (src/laserOdometry.cpp:511-522) + para_q / para_t */
+int aloam_get_odom_stats(aloam_ctx* ctx, int seq, aloam_odom_stats* out);
+
+/* ---- teacher forcing / state injection (what the topic hand-over between the nodes allows) ----------------- */
+int aloam_set_features(aloam_ctx* ctx, int seq, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp,
+                       const float* flat, int n_flat, const float* less_flat, int n_less_flat);   /* the 4 feature topics (src/laserOdometry.cpp:243-258) */
+int aloam_set_last(aloam_ctx* ctx, int seq, const float* corner_last, int n_corner, const float* surf_last, int n_surf); /* laserCloudCornerLast / SurfLast + kd-tree input (src/laserOdometry.cpp:554-568) */
+int aloam_set_state(aloam_ctx* ctx, int seq, const double para_q[4], const double para_t[3], const double q_w_curr[4],
+                    const double t_w_curr[3]);                       /* src/laserOdometry.cpp:93-98              */
+int aloam_set_system_inited(aloam_ctx* ctx, int inited);             /* systemInited (src/laserOdometry.cpp:69,267-271) */
+
+/* ---- intermediate arrays, for parity tests ----------------------------------------------------------------- */
+int aloam_get_ring_ranges(aloam_ctx* ctx, int seq, int* start, int* count);     /* scanStartInd-5 / ring sizes (src/scanRegistration.cpp:246-252) */
+int aloam_get_curvature(aloam_ctx* ctx, int seq, float* out, int cap);          /* cloudCurvature (src/scanRegistration.cpp:66,262)               */
+int aloam_get_labels(aloam_ctx* ctx, int seq, int* out, int cap);               /* cloudLabel (src/scanRegistration.cpp:69)                       */
+/* correspondences of the last outer iteration: edges 9 floats (cp,a,b), planes 12 floats (cp,j,l,m), plus the
+ * index of the query feature each belongs to (src/laserOdometry.cpp:365-381,460-479). */
+int aloam_get_correspondences(aloam_ctx* ctx, int seq, float* edges, int cap_edges, int* n_edges, int* edge_query,
+                              float* planes, int cap_planes, int* n_planes, int* plane_query);
+
+/* ---- per-kernel timing (hipEvents on the context's stream), for bench.py's roofline object ----------------- */
+int aloam_profile_enable(aloam_ctx* ctx, int on);
+int aloam_profile_kernel_count(void);
+const char* aloam_profile_kernel_name(int kernel);
+/* accumulated since the last enable: total milliseconds, launches, algorithmic bytes moved */
+int aloam_profile_get(aloam_ctx* ctx, int kernel, double* total_ms, long long* launches, double* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
