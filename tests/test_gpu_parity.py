@@ -1,0 +1,243 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/aloam_mi355x.h), against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact for every integer / index / f32 feature array; poses within 1e-4 m / 1e-4 rad
+(BASELINE.json north_star) — in practice they agree to ~1e-15 because the f64 sums only differ in association order.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+from conftest import bits_equal, quat_angle
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4
+FEATURES = ("cloud", "sharp", "less_sharp", "flat", "less_flat")
+
+
+def _mk(binding, model, batch=1, max_points=140000, **kw):
+    return binding.Aloam(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field, batch=batch,
+                         max_points=max_points, **kw)
+
+
+def _assert_features_equal(fo, fg, ctx=""):
+    for k in FEATURES:
+        assert fo[k].shape == fg[k].shape, (ctx, k, fo[k].shape, fg[k].shape)
+        assert bits_equal(fo[k], fg[k]), (ctx, k)
+
+
+def _assert_pose_close(po, pg, ctx=""):
+    assert np.abs(po["t_lc"] - pg["t_lc"]).max() < POSE_TOL_M and np.linalg.norm(po["t_w"] - pg["t_w"]) < POSE_TOL_M, (ctx, po, pg)
+    assert quat_angle(po["q_lc"], pg["q_lc"]) < POSE_TOL_RAD and quat_angle(po["q_w"], pg["q_w"]) < POSE_TOL_RAD, (ctx, po, pg)
+
+
+@pytest.mark.parametrize("name,frames,kw", [("VLP-16", 4, {}), ("HDL-32", 3, {}), ("HDL-64", 4, {}), ("HDL-64", 3, {"columns": 2200}),
+                                            ("ROWS128", 2, {})])
+def test_free_running_sequence_matches_oracle(O, binding, sequence, name, frames, kw):
+    """Registration + odometry over consecutive sweeps, every intermediate array compared."""
+    scans, R, t, model = sequence(name, frames, seed=1, **kw)
+    orc = O.Oracle(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field)
+    gpu = _mk(binding, model, max_points=max(len(s) for s in scans) + 64)
+    for k, x in enumerate(scans):
+        fo = orc.scan_register(x)
+        gpu.scan_register(x)
+        fg = gpu.features()
+        _assert_features_equal(fo, fg, (name, k))
+        so, co = orc.ring_ranges(); sg, cg = gpu.ring_ranges()
+        assert np.array_equal(so, sg) and np.array_equal(co, cg)
+        curv_o, lab_o, _ = orc.per_point(); curv_g, lab_g = gpu.per_point()
+        sel = np.zeros(len(curv_o), bool)
+        for s0, c0 in zip(so, co):
+            if c0 >= 17:
+                sel[s0 + 5:s0 + c0 - 6] = True                      # the indices the reference ever reads (scanRegistration.cpp:249-251)
+        assert bits_equal(curv_o[sel], curv_g[sel]) and np.array_equal(lab_o[sel], lab_g[sel])
+        po = orc.odometry_step()
+        gpu.odometry_step()
+        pg = gpu.pose()
+        _assert_pose_close(po, pg, (name, k))
+        so_, sg_ = orc.odom_stats(), gpu.odom_stats()
+        for key in ("corner_corr", "plane_corr", "lm_iterations", "lm_successful", "termination"):
+            assert so_[key] == sg_[key], (name, k, key, so_, sg_)
+        assert np.allclose(so_["final_cost"], sg_["final_cost"], rtol=1e-9)
+        if k > 0:
+            eo, plo, eqo, pqo = orc.correspondences()
+            eg, plg, eqg, pqg = gpu.correspondences()
+            assert np.array_equal(eqo, eqg) and np.array_equal(pqo, pqg)
+            assert bits_equal(eo.astype(np.float32), eg) and bits_equal(plo.astype(np.float32), plg)
+        assert bits_equal(orc.cloud(O.CLOUD_CORNER_LAST), gpu.cloud(binding.CLOUD_CORNER_LAST))
+        assert bits_equal(orc.cloud(O.CLOUD_SURF_LAST), gpu.cloud(binding.CLOUD_SURF_LAST))
+    gpu.close()
+
+
+def test_batched_sequences_are_independent_and_match_oracle(O, binding, sequence):
+    """batch = 3 different sequences in one context == three single oracle runs (no cross-talk between sequences)."""
+    seqs = [sequence("HDL-64", 3, seed=s, columns=1024) for s in (11, 12, 13)]
+    model = seqs[0][3]
+    gpu = _mk(binding, model, batch=3, max_points=64 * 1024)
+    orcs = [O.Oracle(n_scans=64, min_range=model.min_range) for _ in seqs]
+    for k in range(3):
+        gpu.scan_register([s[0][k] for s in seqs])
+        for b, orc in enumerate(orcs):
+            fo = orc.scan_register(seqs[b][0][k])
+            _assert_features_equal(fo, gpu.features(b), (b, k))
+        gpu.odometry_step()
+        for b, orc in enumerate(orcs):
+            _assert_pose_close(orc.odometry_step(), gpu.pose(b), (b, k))
+    gpu.close()
+
+
+def test_teacher_forced_odometry_step(O, binding, sequence):
+    """Odometry alone: features, last clouds and warm start injected from the oracle (isolates stage 2)."""
+    scans, R, t, model = sequence("HDL-64", 3, seed=4, columns=1024)
+    orc = O.Oracle(n_scans=64, min_range=model.min_range)
+    feats = []
+    for x in scans:
+        feats.append(orc.scan_register(x))
+        orc.odometry_step()
+    para_q, para_t = np.array([0.001, -0.002, 0.012, 0.9999]), np.array([0.9, 0.05, -0.01])
+    para_q /= np.linalg.norm(para_q)
+    q_w, t_w = np.array([0.0, 0.0, 0.1, 0.995]), np.array([3.0, 1.0, 0.2])
+    o2 = O.Oracle(n_scans=64, min_range=model.min_range)
+    gpu = _mk(binding, model, max_points=70000)
+    for dev in (o2, gpu):
+        dev.set_features(feats[2])
+        dev.set_last(feats[1]["less_sharp"], feats[1]["less_flat"])
+        dev.set_state(para_q, para_t, q_w, t_w, inited=True)
+        dev.odometry_step()
+    _assert_pose_close(o2.pose(), gpu.pose())
+    assert o2.odom_stats()["corner_corr"] == gpu.odom_stats()["corner_corr"]
+    assert np.abs(gpu.pose()["t_lc"] - para_t).max() > 1e-3               # the solve actually moved the estimate
+    gpu.close()
+
+
+def test_input_layouts_and_nan_filter(O, binding, syn, sequence):
+    """stride-32 PointCloud2 records == stride-16; NaN returns are dropped like removeNaNFromPointCloud does."""
+    scans, R, t, model = sequence("VLP-16", 1, seed=8, nan_fraction=0.03)
+    x = scans[0]
+    assert np.isnan(x[:, 0]).sum() > 100
+    orc = O.Oracle(n_scans=16, min_range=model.min_range)
+    fo = orc.scan_register(x)
+    gpu = _mk(binding, model, max_points=40000)
+    gpu.scan_register(x)
+    _assert_features_equal(fo, gpu.features(), "nan")
+    wide = np.zeros((len(x), 8), np.float32); wide[:, :4] = x; wide[:, 4:] = 123.0
+    gpu.scan_register(wide)
+    _assert_features_equal(fo, gpu.features(), "stride32")
+    gpu.close()
+
+
+def test_edge_cases(O, binding):
+    gpu = binding.Aloam(n_scans=16, min_range=0.3, max_points=4096)
+    for bad in (np.zeros((0, 4), np.float32), np.full((10, 4), np.nan, np.float32), np.full((10, 4), 0.01, np.float32)):
+        with pytest.raises(binding.AloamError) as e:
+            gpu.scan_register(bad)
+        assert e.value.code == binding.E_EMPTY
+    with pytest.raises(binding.AloamError) as e:                          # larger than max_points
+        gpu.scan_register(np.ones((5000, 4), np.float32))
+    assert e.value.code == binding.E_CAPACITY
+    # rings too short to select anything: cloud is produced, no features, odometry still steps
+    tiny = np.array([[5, 0, 0, 0], [5, 1, 0, 0], [5, 2, 0.2, 0]], np.float32)
+    orc = O.Oracle(16, 0.3)
+    fo = orc.scan_register(tiny)
+    gpu.scan_register(tiny)
+    _assert_features_equal(fo, gpu.features(), "tiny")
+    gpu.odometry_step(); gpu.scan_register(tiny); gpu.odometry_step()
+    assert gpu.odom_stats()["termination"] == [4, 4]                      # no residuals
+    assert np.array_equal(gpu.pose()["q_w"], [0, 0, 0, 1])
+    gpu.close()
+    # a ring longer than max_ring_points is reported, not silently truncated
+    g2 = binding.Aloam(n_scans=16, min_range=0.3, max_points=8192, max_ring_points=2059)
+    ang = np.linspace(0, -2 * np.pi, 3000, endpoint=False)
+    ring = np.stack([10 * np.cos(ang), 10 * np.sin(ang), np.zeros_like(ang), np.zeros_like(ang)], 1).astype(np.float32)
+    with pytest.raises(binding.AloamError) as e:
+        g2.scan_register(ring)
+    assert e.value.code == binding.E_CAPACITY
+    g2.close()
+    # odometry before any features
+    g3 = binding.Aloam(n_scans=16, min_range=0.3, max_points=4096)
+    with pytest.raises(binding.AloamError) as e:
+        g3.odometry_step()
+    assert e.value.code == binding.E_STATE
+    g3.close()
+
+
+def test_single_long_ring_uses_large_lds_class(O, binding):
+    """One ring of 3000 points (> 2059): handled by the 4096-key LDS class, bit-exact."""
+    rng = np.random.default_rng(0)
+    ang = np.linspace(np.pi, -np.pi, 3000, endpoint=False)
+    rad = 10 + 3 * np.sign(np.sin(6 * ang)) + rng.normal(size=3000) * 0.02
+    ring = np.stack([rad * np.cos(ang), rad * np.sin(ang), np.tan(np.deg2rad(1.0)) * rad, np.zeros_like(ang)], 1).astype(np.float32)
+    orc = O.Oracle(16, 0.3)
+    fo = orc.scan_register(ring)
+    gpu = binding.Aloam(n_scans=16, min_range=0.3, max_points=4096, max_ring_points=4107)
+    gpu.scan_register(ring)
+    _assert_features_equal(fo, gpu.features(), "long ring")
+    assert len(fo["sharp"]) > 0 and len(fo["less_flat"]) > 100
+    gpu.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
+def test_gpu_reproduces_committed_goldens(binding, path):
+    g = np.load(path)
+    gpu = binding.Aloam(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), max_points=40000)
+    k = 0
+    while f"scan{k}" in g:
+        gpu.scan_register(g[f"scan{k}"])
+        f = gpu.features()
+        for key in ("sharp", "less_sharp", "flat", "less_flat"):
+            assert bits_equal(f[key], g[f"{key}{k}"]), (path, k, key)
+        assert bits_equal(f["cloud"][:, 3], g[f"cloud_intensity{k}"])
+        gpu.odometry_step()
+        p = gpu.pose()
+        assert np.abs(p["t_lc"] - g[f"t_lc{k}"]).max() < POSE_TOL_M and quat_angle(p["q_lc"], g[f"q_lc{k}"]) < POSE_TOL_RAD
+        assert np.linalg.norm(p["t_w"] - g[f"t_w{k}"]) < POSE_TOL_M and quat_angle(p["q_w"], g[f"q_w{k}"]) < POSE_TOL_RAD
+        k += 1
+    gpu.close()
+
+
+def test_full_size_batch_properties(O, binding, syn):
+    """BASELINE size (HDL-64, 131072 points per sweep) in a batch of 8 through the device-resident entry point:
+    size-independent properties + one sequence checked against the oracle."""
+    import torch
+    B, T = 8, 3
+    dev = torch.device("cuda", 0)
+    model = syn.sensor_model("HDL-64", device=dev)
+    NP = model.dirs.shape[0]
+    data = torch.zeros((B, T, NP, 4), dtype=torch.float32, device=dev)
+    counts = np.zeros((B, T), np.int32)
+    world = syn.make_world(321).to(dev)
+    for b in range(B):
+        R, t = syn.trajectory(T, seed=40 + b, start_angle=0.5 * b)
+        gen = torch.Generator(device=dev).manual_seed(40 + b)
+        for k in range(T):
+            s = syn.render_scan(world, model, R[k], t[k], 0.02, gen)
+            counts[b, k] = len(s); data[b, k, :len(s)] = s
+    torch.cuda.synchronize()
+    gpu = _mk(binding, model, batch=B, max_points=NP, max_ring_points=2059)
+    host0 = data[0].cpu().numpy()
+    orc = O.Oracle(n_scans=64, min_range=model.min_range)
+    for k in range(T):
+        gpu.process_device(data.data_ptr() + k * NP * 16, T * NP * 16, counts[:, k])
+        gpu.synchronize()
+        orc.scan_register(host0[k, :counts[0, k]])
+        po = orc.odometry_step()
+        _assert_pose_close(po, gpu.pose(0), k)
+        assert bits_equal(orc.cloud(O.CLOUD_SURF_LAST), gpu.cloud(binding.CLOUD_SURF_LAST, 0))
+        for b in range(B):
+            cl = gpu.cloud(binding.CLOUD_FULL, b)
+            s0, c0 = gpu.ring_ranges(b)
+            assert c0.sum() == len(cl) and c0[51:].sum() == 0 and len(cl) > 90000
+            assert np.all(np.floor(cl[:, 3] + 0.06) == np.repeat(np.arange(64), c0))          # ring-sorted, stable compaction
+            sharp, less = gpu.cloud(binding.CLOUD_SHARP, b), gpu.cloud(binding.CLOUD_CORNER_LAST, b)
+            assert {p.tobytes() for p in sharp} <= {p.tobytes() for p in less}
+            assert len(sharp) <= 12 * 51 and len(gpu.cloud(binding.CLOUD_FLAT, b)) <= 24 * 51
+    # the estimated motion is ~1 m per sweep for every sequence
+    for b in range(B):
+        assert 0.8 < np.linalg.norm(gpu.pose(b)["t_lc"]) < 1.2
+    # idempotence: replaying the last sweep into a fresh context reproduces its registration bit-for-bit
+    g2 = _mk(binding, model, batch=B, max_points=NP, max_ring_points=2059)
+    g2.scan_register_device(data.data_ptr() + (T - 1) * NP * 16, T * NP * 16, counts[:, T - 1])
+    g2.synchronize()
+    for b in range(B):
+        assert bits_equal(g2.cloud(binding.CLOUD_LESS_FLAT, b), gpu.cloud(binding.CLOUD_SURF_LAST, b))
+    g2.close(); gpu.close()
