@@ -16,11 +16,11 @@
 using namespace aloam;
 
 namespace {
-enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_COMPACT, K_NN_CORNER, K_NN_PLANE,
-                K_WALK_CORNER, K_WALK_PLANE, K_SOLVE, K_ADVANCE, K_COUNT };
+enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_COMPACT, K_BUILD_GRIDS, K_ASSOC_CORNER,
+                K_ASSOC_PLANE, K_SOLVE, K_ADVANCE, K_COUNT };
 const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_classify", "k_ring_offsets", "k_scatter", "k_ring_features",
-                                     "k_compact_features", "k_nn_search[corner]", "k_nn_search[plane]", "k_walk_corner",
-                                     "k_walk_plane", "k_solve", "k_advance"};
+                                     "k_compact_features", "k_build_grids", "k_associate[corner]", "k_associate[plane]",
+                                     "k_solve", "k_advance"};
 struct ProfRec { int kernel; hipEvent_t e0, e1; };
 }  // namespace
 
@@ -44,7 +44,11 @@ struct aloam_ctx {
   float4* d_less_flat[2] = {nullptr, nullptr};
   int cur = 0;                       // which of the double buffers holds the CURRENT sweep's less-sharp / less-flat
   OdomState* d_state = nullptr;
-  unsigned long long *d_nn_corner = nullptr, *d_nn_surf = nullptr;
+  float4* d_grid_sorted3[2] = {nullptr, nullptr}; float4* d_grid_sorted2[2] = {nullptr, nullptr};
+  int* d_grid_start3[2] = {nullptr, nullptr}; int* d_grid_start2[2] = {nullptr, nullptr};
+  int* d_grid_first_ge[2] = {nullptr, nullptr}; int* d_grid_last_le[2] = {nullptr, nullptr}; int* d_grid_flags[2] = {nullptr, nullptr};
+  int grid_H[2] = {4096, 16384};
+  bool grids_valid = false;          // the grids describe the current "last" clouds
   EdgeRec* d_edges = nullptr; PlaneRec* d_planes = nullptr;
   bool system_inited = false;        // reference src/laserOdometry.cpp:69
   bool have_features = false;
@@ -121,7 +125,13 @@ OdomArgs odom_args(aloam_ctx* c) {
   a.meta = c->d_meta; a.state = c->d_state;
   a.sharp = c->d_sharp; a.flat = c->d_flat;
   a.corner_last = c->d_less_sharp[1 - c->cur]; a.surf_last = c->d_less_flat[1 - c->cur];
-  a.nn_corner = c->d_nn_corner; a.nn_surf = c->d_nn_surf; a.edges = c->d_edges; a.planes = c->d_planes;
+  for (int k = 0; k < 2; ++k) {
+    a.grid_sorted3[k] = c->d_grid_sorted3[k]; a.grid_sorted2[k] = c->d_grid_sorted2[k]; a.grid_start3[k] = c->d_grid_start3[k];
+    a.grid_start2[k] = c->d_grid_start2[k]; a.grid_first_ge[k] = c->d_grid_first_ge[k]; a.grid_last_le[k] = c->d_grid_last_le[k];
+    a.grid_flags[k] = c->d_grid_flags[k];
+  }
+  a.grid_H_corner = c->grid_H[0]; a.grid_H_surf = c->grid_H[1];
+  a.edges = c->d_edges; a.planes = c->d_planes;
   a.lm_max_iterations = c->cfg.lm_max_iterations;
   return a;
 }
@@ -226,8 +236,16 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
     if ((rc = dmalloc(c, &c->d_less_flat[k], B * cap))) return rc;
   }
   if ((rc = dmalloc(c, &c->d_state, B))) return rc;
-  if ((rc = dmalloc(c, &c->d_nn_corner, B * R * 12))) return rc;
-  if ((rc = dmalloc(c, &c->d_nn_surf, B * R * 24))) return rc;
+  for (int k = 0; k < 2; ++k) {
+    const size_t per = k == 0 ? R * 120 : cap;
+    if ((rc = dmalloc(c, &c->d_grid_sorted3[k], B * per))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_sorted2[k], B * per))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_start3[k], B * (c->grid_H[k] + 1)))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_start2[k], B * (c->grid_H[k] + 1)))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_first_ge[k], B * (R + 8)))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_last_le[k], B * (R + 8)))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_flags[k], B * 4))) return rc;
+  }
   if ((rc = dmalloc(c, &c->d_edges, B * R * 12))) return rc;
   if ((rc = dmalloc(c, &c->d_planes, B * R * 24))) return rc;
   // identity poses (src/laserOdometry.cpp:93-98)
@@ -246,8 +264,10 @@ void aloam_destroy(aloam_ctx* c) {
   for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
   void* bufs[] = {c->d_in, c->d_nin, c->d_meta, c->d_ringid, c->d_ori, c->d_hist, c->d_blockoff, c->d_ringstart, c->d_cloud, c->d_curv,
                   c->d_label, c->d_sharp_idx, c->d_less_sharp_idx, c->d_flat_idx, c->d_pick_cnt, c->d_lf_ring, c->d_lf_cnt, c->d_sharp,
-                  c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_nn_corner,
-                  c->d_nn_surf, c->d_edges, c->d_planes};
+                  c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes,
+                  c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
+                  c->d_grid_start2[0], c->d_grid_start2[1], c->d_grid_first_ge[0], c->d_grid_first_ge[1], c->d_grid_last_le[0], c->d_grid_last_le[1],
+                  c->d_grid_flags[0], c->d_grid_flags[1]};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -302,15 +322,12 @@ int aloam_odometry_step(aloam_ctx* c) {
   } else {
     OdomArgs a = odom_args(c);
     const int max_sharp = c->R * 12, max_flat = c->R * 24;
+    { ProfScope p(c, K_BUILD_GRIDS); launch_build_grids(a, c->stream); }          // kd-tree stand-in over the last clouds
     for (int outer = 0; outer < c->cfg.outer_iterations; ++outer) {
       a.outer = outer;
       a.last_outer = outer == c->cfg.outer_iterations - 1;
-      HIP_TRY(c, hipMemsetAsync(c->d_nn_corner, 0xff, sizeof(unsigned long long) * c->B * max_sharp, c->stream));
-      HIP_TRY(c, hipMemsetAsync(c->d_nn_surf, 0xff, sizeof(unsigned long long) * c->B * max_flat, c->stream));
-      { ProfScope p(c, K_NN_CORNER); launch_nn_search(a, 0, max_sharp, c->R * 120, c->stream); }
-      { ProfScope p(c, K_NN_PLANE); launch_nn_search(a, 1, max_flat, c->cap, c->stream); }
-      { ProfScope p(c, K_WALK_CORNER); launch_walk_corner(a, max_sharp, c->stream); }
-      { ProfScope p(c, K_WALK_PLANE); launch_walk_plane(a, max_flat, c->stream); }
+      { ProfScope p(c, K_ASSOC_CORNER); launch_associate(a, false, max_sharp, c->stream); }
+      { ProfScope p(c, K_ASSOC_PLANE); launch_associate(a, true, max_flat, c->stream); }
       { ProfScope p(c, K_SOLVE); launch_solve(a, c->stream); }
     }
   }
@@ -544,10 +561,9 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
         case K_SCATTER: bytes += 21 * Nin + 16 * N; break;
         case K_RING_FEATURES: bytes += 16 * N + 5 * N + 16 * Ls; break;
         case K_COMPACT: bytes += 32 * (Fc + Lc + Fs) + 32 * Ls; break;
-        case K_NN_CORNER: bytes += 16 * (Fc + Lcl) + 8 * Fc; break;
-        case K_NN_PLANE: bytes += 16 * (Fs + Lsl) + 8 * Fs; break;
-        case K_WALK_CORNER: bytes += 16 * (Fc + Lcl) + 48 * Fc; break;
-        case K_WALK_PLANE: bytes += 16 * (Fs + Lsl) + 64 * Fs; break;
+        case K_BUILD_GRIDS: bytes += 16 * (Lcl + Lsl) + 32 * (Lcl + Lsl) + 8.0 * (c->grid_H[0] + c->grid_H[1]); break;
+        case K_ASSOC_CORNER: bytes += 16 * (Fc + Lcl) + 48 * Fc; break;
+        case K_ASSOC_PLANE: bytes += 16 * (Fs + Lsl) + 64 * Fs; break;
         case K_SOLVE: bytes += 9.0 * (48 * Fc + 64 * Fs); break;
         default: break;
       }

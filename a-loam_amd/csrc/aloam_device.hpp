@@ -83,14 +83,40 @@ struct OdomArgs {
   const float4* flat;        // [B][R*24]
   const float4* corner_last; // [B][R*120]
   const float4* surf_last;   // [B][cap]
-  unsigned long long* nn_corner;   // [B][R*12]
-  unsigned long long* nn_surf;     // [B][R*24]
+  // spatial hash grids over the last clouds (k_build_grids): index 0 = corner_last, 1 = surf_last
+  float4* grid_sorted3[2];   // [B][R*120] / [B][cap]   entries bucketed by (ix,iy,iz)
+  float4* grid_sorted2[2];   //                          entries bucketed by (ix,iy,ring key)
+  int* grid_start3[2];       // [B][H+1]
+  int* grid_start2[2];       // [B][H+1]
+  int* grid_first_ge[2];     // [B][R+8]
+  int* grid_last_le[2];      // [B][R+8]
+  int* grid_flags[2];        // [B][4]   flags[0] != 0: cloud not ring-sorted / out of range -> literal brute-force path
+  int grid_H_corner, grid_H_surf;   // buckets (power of two, multiple of 1024)
   EdgeRec* edges;            // [B][R*12]
   PlaneRec* planes;          // [B][R*24]
   int outer;                 // which outer iteration (0/1)
   int last_outer;            // 1: integrate the pose after solving (src/laserOdometry.cpp:504-505)
   int lm_max_iterations;
 };
+
+struct GridView {
+  int H;
+  float4 *sorted3, *sorted2;
+  int *start3, *start2, *first_ge, *last_le, *flags;
+};
+__device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int which) {
+  GridView g;
+  g.H = which == 0 ? a.grid_H_corner : a.grid_H_surf;
+  const long long per = which == 0 ? (long long)a.R * 120 : (long long)a.cap;
+  g.sorted3 = a.grid_sorted3[which] + b * per;
+  g.sorted2 = a.grid_sorted2[which] + b * per;
+  g.start3 = a.grid_start3[which] + (long long)b * (g.H + 1);
+  g.start2 = a.grid_start2[which] + (long long)b * (g.H + 1);
+  g.first_ge = a.grid_first_ge[which] + (long long)b * (a.R + 8);
+  g.last_le = a.grid_last_le[which] + (long long)b * (a.R + 8);
+  g.flags = a.grid_flags[which] + b * 4;
+  return g;
+}
 
 __device__ __forceinline__ float4 load_point(const char* base, long long i, int stride) {
   const float* p = reinterpret_cast<const float*>(base + i * (long long)stride);

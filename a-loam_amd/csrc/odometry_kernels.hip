@@ -2,12 +2,14 @@
 //
 // Replaces, for a BATCH of independent sequences, the solve part of the laserOdometry main loop
 // (reference src/laserOdometry.cpp:274-506) and the third-party calls inside it:
-//   k_nn_search   TransformToStart (:111-129) + pcl::KdTreeFLANN::nearestKSearch(k=1) (:302,390): exact brute force
-//                 over target tiles staged in LDS; one lane per query, broadcast ds_read_b128 per target, the f32
-//                 distance ((dx*dx+dy*dy)+dz*dz) FLANN's L2_Simple accumulates; tiles merge through a packed
-//                 (distance bits, index) 64-bit atomicMin, so the lowest index wins exact ties.
-//   k_walk_corner the ring-adjacent second neighbour walk for edge features (:304-384), one wave per query
-//   k_walk_plane  the two-neighbour walk for planar features (:392-482), one wave per query
+//   k_build_grids pcl::KdTreeFLANN::setInputCloud (:567-568): LDS counting-sort of each "last" cloud into two spatial
+//                 hash grids + the ring-key index tables that turn the reference's walk-until-break loops into
+//                 index windows
+//   k_associate   TransformToStart (:111-129) + nearestKSearch(k=1) (:302,390) + the ring-adjacent second / third
+//                 neighbour walks (:304-384, :392-482), one wave per query: exact 1-NN by expanding cubic shells of
+//                 hash cells with the f32 distance ((dx*dx+dy*dy)+dz*dz) FLANN's L2_Simple accumulates (lowest index
+//                 wins exact ties), then the walk candidates through the (x, y, ring) grid; clouds that are not
+//                 ring-sorted fall back to the literal brute-force loops inside the same kernel
 //   k_solve       ceres::Problem + ceres::Solve (:284-291,380-381,478-479,494-499): per-correspondence
 //                 LidarEdgeFactor / LidarPlaneFactor residual + closed-form Jacobian (reference src/lidarFactor.hpp:
 //                 18-43,68-90), Huber(0.1) re-weighting, reduction to the 6x6 J^T J / J^T r / cost with wave64
@@ -40,40 +42,98 @@ __device__ __forceinline__ float4 transform_to_start(const float4& p, const Odom
 }
 
 // -------------------------------------------------------------------------------------------------------
-// grid (tile slots, query tiles, B); which = 0 corners (sharp vs corner_last), 1 planes (flat vs surf_last).
-// Each workgroup strides over the target tiles (the true target count is only known on the device).
-__global__ __launch_bounds__(256) void k_nn_search(OdomArgs a, int which) {
-  const int b = blockIdx.z, tid = threadIdx.x;
+// Spatial hash grids over the "last" clouds (stand-in for pcl::KdTreeFLANN::setInputCloud, reference
+// src/laserOdometry.cpp:567-568).  Two grids per cloud, both built by one 1024-thread workgroup per (sequence, cloud)
+// with LDS counting sort (count -> exclusive scan -> fill):
+//   G3: key (ix, iy, iz)      cell kCell3  — exact 1-NN by expanding cubic shells
+//   G2: key (ix, iy, ringkey) cell kCell2  — the ring-adjacent second / third neighbour search
+// A grid entry is {x, y, z, bits(idx | (ringkey + 1) << 20)}: one 16-B load per candidate.  Cell sizes are powers
+// of two so p * inv_cell is exact up to the f32 rounding of the product.
+// Also per cloud: first_ge[v] = first index whose ring key (int(intensity)) is >= v, last_le[v] = last index
+// whose key is <= v.  They turn the reference's walk-until-break loops into index windows whenever the cloud is
+// ring-sorted the way scan registration emits it; clouds that are not (possible through aloam_set_last) and
+// clouds with huge coordinates are flagged and served by the literal brute-force path instead.
+constexpr float kCell3Surf = 0.5f, kCell3Corner = 1.0f, kCell2 = 1.0f;
+constexpr unsigned kIdxMask = (1u << 20) - 1u;
+__device__ __forceinline__ float cell3_of(int which) { return which == 0 ? kCell3Corner : kCell3Surf; }
+
+__device__ __forceinline__ unsigned hash3(int a, int b, int c) {
+  return ((unsigned)a * 73856093u) ^ ((unsigned)b * 19349663u) ^ ((unsigned)c * 83492791u);
+}
+
+__global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
+  const int b = blockIdx.y, which = blockIdx.x, tid = threadIdx.x;      // which: 0 corner_last, 1 surf_last
   const SeqMeta m = a.meta[b];
-  const int nq = which == 0 ? m.n_sharp : m.n_flat;
-  const int nt = which == 0 ? m.n_corner_last : m.n_surf_last;
-  const int q0 = blockIdx.y * 256;
-  if (q0 >= nq || (int)blockIdx.x * kNnTile >= nt) return;
-  const float4* queries = which == 0 ? a.sharp + (long long)b * a.R * 12 : a.flat + (long long)b * a.R * 24;
-  const float4* targets = which == 0 ? a.corner_last + (long long)b * a.R * 120 : a.surf_last + (long long)b * a.cap;
-  unsigned long long* nn = which == 0 ? a.nn_corner + (long long)b * a.R * 12 : a.nn_surf + (long long)b * a.R * 24;
-  __shared__ float4 tile[kNnTile];
-  const int qi = q0 + tid;
-  float4 sel = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (qi < nq) sel = transform_to_start(queries[qi], a.state[b]);
-  float best = __int_as_float(0x7f800000);
-  int besti = -1;
-  for (int t0 = blockIdx.x * kNnTile; t0 < nt; t0 += gridDim.x * kNnTile) {
-    const int tc = (nt - t0 < kNnTile) ? nt - t0 : kNnTile;
-    __syncthreads();
-    for (int t = tid; t < tc; t += 256) tile[t] = targets[t0 + t];
-    __syncthreads();
-#pragma unroll 4
-    for (int t = 0; t < tc; ++t) {
-      const float4 p = tile[t];
-      const float dx = p.x - sel.x, dy = p.y - sel.y, dz = p.z - sel.z;
-      const float d = (dx * dx + dy * dy) + dz * dz;
-      if (d < best) { best = d; besti = t0 + t; }
-    }
+  const int n = which == 0 ? m.n_corner_last : m.n_surf_last;
+  const float4* pts = which == 0 ? a.corner_last + (long long)b * a.R * 120 : a.surf_last + (long long)b * a.cap;
+  const GridView g = grid_view(a, b, which);
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  int* cnt = lds;                         // [H]
+  int* part = lds + g.H;                  // [1024]
+  int* tab = part + 1024;                 // first_eq [KT], last_eq [KT], flags[4]
+  const int KT = a.R + 8;
+  for (int k = tid; k < KT; k += 1024) { tab[k] = 0x7fffffff; tab[KT + k] = -1; }
+  if (tid < 4) tab[2 * KT + tid] = 0;
+  __syncthreads();
+  // pass 0: ring-key tables + sanity flags
+  int bad = 0;
+  for (int i = tid; i < n; i += 1024) {
+    const float4 p = pts[i];
+    const int key = (int)p.w;
+    if (key < 0 || key > a.R || !(fabsf(p.x) < 4096.f && fabsf(p.y) < 4096.f && fabsf(p.z) < 4096.f)) bad = 1;
+    else { atomicMin(&tab[key + 4], i); atomicMax(&tab[KT + key + 4], i); }
   }
-  if (qi < nq && besti >= 0) {
-    const unsigned long long packed = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)besti;
-    atomicMin(&nn[qi], packed);
+  if (bad) atomicOr(&tab[2 * KT], 1);
+  if (n >= (1 << 20)) tab[2 * KT] = 1;
+  __syncthreads();
+  const int is_bad = tab[2 * KT];
+  if (tid == 0) {
+    // first_ge[v]: suffix min of first_eq; last_le[v]: prefix max of last_eq.  table index = v + 4, v in [-4, R+3]
+    int run = 0x7fffffff;
+    for (int k = KT - 1; k >= 0; --k) { run = tab[k] < run ? tab[k] : run; g.first_ge[k] = is_bad ? -1 : run; }
+    run = -1;
+    for (int k = 0; k < KT; ++k) { run = tab[KT + k] > run ? tab[KT + k] : run; g.last_le[k] = is_bad ? 0x7fffffff : run; }
+    g.flags[0] = is_bad;
+  }
+  if (is_bad) return;
+  for (int pass = 0; pass < 2; ++pass) {          // 0: G3, 1: G2
+    const float inv = pass == 0 ? 1.0f / cell3_of(which) : 1.0f / kCell2;
+    int* start = pass == 0 ? g.start3 : g.start2;
+    float4* sorted = pass == 0 ? g.sorted3 : g.sorted2;
+    __syncthreads();
+    for (int h = tid; h < g.H; h += 1024) cnt[h] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+      const float4 p = pts[i];
+      const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+      const int iz = pass == 0 ? (int)floorf(p.z * inv) : (int)p.w;
+      atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[H]: per-thread run of H/1024 consecutive buckets + scan of the 1024 partial sums
+    const int per = g.H / 1024;
+    int local = 0;
+    for (int k = 0; k < per; ++k) local += cnt[tid * per + k];
+    part[tid] = local;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const int v = tid >= d ? part[tid - d] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    int run = part[tid] - local;
+    for (int k = 0; k < per; ++k) { const int c = cnt[tid * per + k]; cnt[tid * per + k] = run; start[tid * per + k] = run; run += c; }
+    if (tid == 1023) start[g.H] = run;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+      const float4 p = pts[i];
+      const int key = (int)p.w;
+      const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+      const int iz = pass == 0 ? (int)floorf(p.z * inv) : key;
+      const int pos = atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
+      sorted[pos] = make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)i | ((unsigned)(key + 1) << 20)));
+    }
   }
 }
 
@@ -86,177 +146,227 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
   return v;
 }
 
-// -------------------------------------------------------------------------------------------------------
-// One wave per sharp query.  Candidates are ordered exactly as the reference visits them (upward walk from
-// closest+1, then downward from closest-1); "first strictly smaller wins" becomes a lexicographic
-// (distance, visit order) minimum.
-__global__ __launch_bounds__(256) void k_walk_corner(OdomArgs a) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const SeqMeta m = a.meta[b];
-  if (qi >= m.n_sharp) return;
-  const float4* CL = a.corner_last + (long long)b * a.R * 120;
-  const int nt = m.n_corner_last;
-  EdgeRec* rec = a.edges + (long long)b * a.R * 12 + qi;
-  const float4 raw = a.sharp[(long long)b * a.R * 12 + qi];
-  const unsigned long long packed = a.nn_corner[(long long)b * a.R * 12 + qi];
-  const unsigned idx = (unsigned)packed;
-  const float nnd = __uint_as_float((unsigned)(packed >> 32));
-  int valid = 0;
-  int closest = -1, min2 = -1;
-  if (idx != 0xffffffffu && (double)nnd < 25.0) {                     // DISTANCE_SQ_THRESHOLD (:65,305)
-    closest = (int)idx;
-    const float4 sel = transform_to_start(raw, a.state[b]);
-    const int cid = (int)CL[closest].w;                               // closestPointScanID (:308)
-    unsigned long long best = ~0ull;
-    // upward (:312-335)
-    for (int base = closest + 1; base < nt; base += 64) {
-      const int j = base + lane;
-      bool stop = false, cand = false;
-      float d = 0.f;
-      if (j < nt) {
-        const float4 p = CL[j];
-        const int key = (int)p.w;
-        if (key > cid) {                                              // `<= cid` -> continue
-          if ((double)key > (double)cid + 2.5) stop = true;           // NEARBY_SCAN (:66,319)
-          else { d = walk_dist(p, sel); cand = (double)d < 25.0; }
-        }
-      }
-      const unsigned long long sm = __ballot(stop);
-      const int first_stop = sm ? (__ffsll((long long)sm) - 1) : 64;
-      if (cand && lane < first_stop) {
-        const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(j - closest);
-        if (v < best) best = v;
-      }
-      if (sm) break;
+// ---- shell enumeration -------------------------------------------------------------------------------------
+// Square ring of Chebyshev radius r >= 1 in 2-D: 8 r cells, t in [0, 8r).
+__device__ __forceinline__ void ring2d(int r, int t, int* dx, int* dy) {
+  const int w = 2 * r + 1;
+  if (t < w) { *dx = -r + t; *dy = -r; }
+  else if (t < 2 * w) { *dx = -r + (t - w); *dy = r; }
+  else { const int u = t - 2 * w, side = u / (w - 2); *dy = -r + 1 + u % (w - 2); *dx = side ? r : -r; }
+}
+// Cubic shell of Chebyshev radius r >= 1 in 3-D: 24 r^2 + 2 cells.
+__device__ __forceinline__ void shell3d(int r, int c, int* dx, int* dy, int* dz) {
+  const int w = 2 * r + 1, nface = w * w;
+  if (c < 2 * nface) { const int f = c / nface, q = c % nface; *dz = f ? r : -r; *dy = q / w - r; *dx = q % w - r; }
+  else { const int q = c - 2 * nface; *dz = -r + 1 + q / (8 * r); ring2d(r, q % (8 * r), dx, dy); }
+}
+
+// Load-balanced sweep over the buckets the lanes looked up: lane L owns bucket [s0, s0 + cnt); all 64 lanes then share
+// the concatenated candidate list (exclusive prefix by shuffles, owner found by a 6-step binary search over the
+// prefix through ds_bpermute), so every candidate costs one independent 16-B load instead of a per-lane serial chain.
+template <class F>
+__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, F&& f) {
+  int incl = cnt;
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+  const int total = __shfl(incl, 63, 64);
+  const int excl = incl - cnt;
+  for (int base = 0; base < total; base += 64) {
+    const int i = base + lane;
+    int lo = 0, hi = 63;
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+      const int mid = (lo + hi + 1) >> 1;
+      const int e = __shfl(excl, mid, 64);
+      if (e <= i) lo = mid; else hi = mid - 1;
     }
-    // downward (:338-361)
-    for (int base = closest - 1; base >= 0; base -= 64) {
-      const int j = base - lane;
-      bool stop = false, cand = false;
-      float d = 0.f;
-      if (j >= 0) {
-        const float4 p = CL[j];
-        const int key = (int)p.w;
-        if (key < cid) {                                              // `>= cid` -> continue
-          if ((double)key < (double)cid - 2.5) stop = true;
-          else { d = walk_dist(p, sel); cand = (double)d < 25.0; }
-        }
-      }
-      const unsigned long long sm = __ballot(stop);
-      const int first_stop = sm ? (__ffsll((long long)sm) - 1) : 64;
-      if (cand && lane < first_stop) {
-        const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | (0x40000000u + (unsigned)(closest - j));
-        if (v < best) best = v;
-      }
-      if (sm) break;
-    }
-    best = wave_min_u64(best);
-    if (best != ~0ull) {
-      const unsigned seq = (unsigned)best;
-      min2 = seq >= 0x40000000u ? closest - (int)(seq - 0x40000000u) : closest + (int)seq;
-      valid = 1;
-    }
-  }
-  if (lane == 0) {
-    EdgeRec e;
-    e.valid = valid;
-    e.pad[0] = e.pad[1] = 0;
-    e.cp[0] = raw.x; e.cp[1] = raw.y; e.cp[2] = raw.z;                // raw, untransformed point (:365-367)
-    if (valid) {
-      const float4 pa = CL[closest], pb = CL[min2];
-      e.a[0] = pa.x; e.a[1] = pa.y; e.a[2] = pa.z;
-      e.b[0] = pb.x; e.b[1] = pb.y; e.b[2] = pb.z;
-    } else {
-      e.a[0] = e.a[1] = e.a[2] = e.b[0] = e.b[1] = e.b[2] = 0.f;
-    }
-    *rec = e;
+    const int os = __shfl(s0, lo, 64), oe = __shfl(excl, lo, 64);
+    if (i < total) f(sorted[os + (i - oe)]);
   }
 }
 
+// Exact 1-NN of `sel` (pcl::KdTreeFLANN::nearestKSearch(k = 1), reference src/laserOdometry.cpp:302,390) by one wave.
+// Returns packed (f32 distance bits << 32 | index), ~0 if nothing was found.  Distances >= 25 are not needed by
+// the caller (DISTANCE_SQ_THRESHOLD), so the grid search stops once every unvisited point is provably >= 5 m away.
+__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int which, const float4* pts, int n, const float4& sel, int lane) {
+  unsigned long long best = ~0ull;
+  auto visit = [&](const float4& p) {
+    const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
+    const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;
+    const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | (__float_as_uint(p.w) & kIdxMask);
+    if (v < best) best = v;
+  };
+  if (g.flags[0] == 0) {
+    const float cell = cell3_of(which), inv = 1.0f / cell;
+    const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv), cz = (int)floorf(sel.z * inv);
+    for (int r = 1;; ++r) {
+      const int ncell = r == 1 ? 27 : 24 * r * r + 2;            // first step: the whole 3x3x3 cube
+      for (int cb = 0; cb < ncell; cb += 64) {
+        const int c = cb + lane;
+        int s0 = 0, cnt = 0;
+        if (c < ncell) {
+          int dx, dy, dz;
+          if (r == 1) { dz = c / 9 - 1; dy = (c % 9) / 3 - 1; dx = c % 3 - 1; }
+          else shell3d(r, c, &dx, &dy, &dz);
+          const unsigned h = hash3(cx + dx, cy + dy, cz + dz) & (unsigned)(g.H - 1);
+          s0 = g.start3[h];
+          cnt = g.start3[h + 1] - s0;
+        }
+        wave_sweep(g.sorted3, s0, cnt, lane, visit);
+      }
+      best = wave_min_u64(best);
+      const float bound = ((float)r - 0.01f) * cell, b2 = bound * bound;   // every unvisited point is farther than `bound`
+      if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= b2) break;
+      if (b2 >= 25.0f) break;                                       // nothing within DISTANCE_SQ_THRESHOLD is left
+    }
+    return best;
+  }
+  for (int base = 0; base < n; base += 64) {                      // literal brute force (flagged clouds only)
+    const int j = base + lane;
+    if (j < n) {
+      const float4 p = pts[j];
+      visit(make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)j)));
+    }
+  }
+  return wave_min_u64(best);
+}
+
 // -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_walk_plane(OdomArgs a) {
+// Data association for one feature class, one wave per query (4 queries per workgroup):
+//   PLANE = false: corner features  (reference src/laserOdometry.cpp:299-384)  -> EdgeRec
+//   PLANE = true : planar features  (reference src/laserOdometry.cpp:387-483)  -> PlaneRec
+// Candidates of the ring walk are ordered exactly as the reference visits them (upward from closest+1, then
+// downward from closest-1); "first strictly smaller wins" is the lexicographic (distance, visit order) minimum.
+template <bool PLANE>
+__global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
   const SeqMeta m = a.meta[b];
-  if (qi >= m.n_flat) return;
-  const float4* SL = a.surf_last + (long long)b * a.cap;
-  const int nt = m.n_surf_last;
-  PlaneRec* rec = a.planes + (long long)b * a.R * 24 + qi;
-  const float4 raw = a.flat[(long long)b * a.R * 24 + qi];
-  const unsigned long long packed = a.nn_surf[(long long)b * a.R * 24 + qi];
-  const unsigned idx = (unsigned)packed;
-  const float nnd = __uint_as_float((unsigned)(packed >> 32));
-  int valid = 0;
-  int closest = -1, min2 = -1, min3 = -1;
-  if (idx != 0xffffffffu && (double)nnd < 25.0) {
-    closest = (int)idx;
-    const float4 sel = transform_to_start(raw, a.state[b]);
-    const int cid = (int)SL[closest].w;
+  const int nq = PLANE ? m.n_flat : m.n_sharp;
+  if (qi >= nq) return;
+  const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
+  const float4* T = PLANE ? a.surf_last + (long long)b * a.cap : a.corner_last + (long long)b * a.R * 120;
+  const float4 raw = PLANE ? a.flat[(long long)b * a.R * 24 + qi] : a.sharp[(long long)b * a.R * 12 + qi];
+  const GridView g = grid_view(a, b, PLANE ? 1 : 0);
+  const float4 sel = transform_to_start(raw, a.state[b]);
+  int valid = 0, closest = -1, min2 = -1, min3 = -1;
+  const unsigned long long nn = nt > 0 ? wave_nn(g, PLANE ? 1 : 0, T, nt, sel, lane) : ~0ull;
+  const float nnd = __uint_as_float((unsigned)(nn >> 32));
+  if (nn != ~0ull && (double)nnd < 25.0) {                            // DISTANCE_SQ_THRESHOLD (:65,305,393)
+    closest = (int)(unsigned)nn;
+    const int cid = (int)T[closest].w;                                // closestPointScanID (:308,398)
     unsigned long long best2 = ~0ull, best3 = ~0ull;
-    // upward (:402-427): same-or-lower ring -> min2, higher ring -> min3
-    for (int base = closest + 1; base < nt; base += 64) {
-      const int j = base + lane;
-      bool stop = false, c2 = false, c3 = false;
-      float d = 0.f;
-      if (j < nt) {
-        const float4 p = SL[j];
-        const int key = (int)p.w;
-        if ((double)key > (double)cid + 2.5) stop = true;
-        else { d = walk_dist(p, sel); const bool in = (double)d < 25.0; c2 = in && key <= cid; c3 = in && key > cid; }
+    const int jup = g.first_ge[cid + 3 + 4], jdown = g.last_le[cid - 3 + 4];
+    auto consider = [&](const float4& p, int j, int key) {
+      if (j == closest) return;
+      const bool up = j > closest;
+      bool c2, c3;
+      if (PLANE) { c2 = up ? key <= cid : key >= cid; c3 = !c2; }     // :416-426, :444-454
+      else { c2 = up ? key > cid : key < cid; c3 = false; }           // :315-316, :341-342 (`continue` on the same side)
+      const float d = walk_dist(p, sel);
+      if (!((double)d < 25.0)) return;
+      const unsigned seq = up ? (unsigned)(j - closest) : 0x40000000u + (unsigned)(closest - j);
+      const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | seq;
+      if (c2 && v < best2) best2 = v;
+      if (c3 && v < best3) best3 = v;
+    };
+    if (g.flags[0] == 0 && jup > closest && jdown < closest) {
+      // window form: candidates are exactly the indices (jdown, jup) \ {closest}; their keys lie in cid-2 .. cid+2
+      const float inv = 1.0f / kCell2;
+      const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv);
+      auto visit = [&](const float4& p) {
+        const unsigned wb = __float_as_uint(p.w);
+        const int j = (int)(wb & kIdxMask), pk = (int)(wb >> 20) - 1;
+        if (j > jdown && j < jup) consider(p, j, pk);
+      };
+      for (int r = 1;; ++r) {
+        const int ncell = r == 1 ? 9 : 8 * r, nlook = ncell * 5;      // first step: the whole 3x3 block, 5 ring keys each
+        for (int cb = 0; cb < nlook; cb += 64) {
+          const int c = cb + lane;
+          int s0 = 0, cnt = 0;
+          if (c < nlook) {
+            const int key = cid + c % 5 - 2, cc = c / 5;
+            int dx, dy;
+            if (r == 1) { dy = cc / 3 - 1; dx = cc % 3 - 1; } else ring2d(r, cc, &dx, &dy);
+            if (key >= 0) {
+              const unsigned h = hash3(cx + dx, cy + dy, key) & (unsigned)(g.H - 1);
+              s0 = g.start2[h];
+              cnt = g.start2[h + 1] - s0;
+            }
+          }
+          wave_sweep(g.sorted2, s0, cnt, lane, visit);
+        }
+        best2 = wave_min_u64(best2);
+        if (PLANE) best3 = wave_min_u64(best3);
+        const float bound = ((float)r - 0.01f) * kCell2, b2 = bound * bound;
+        if (b2 >= 25.0f) break;
+        const bool done2 = best2 != ~0ull && __uint_as_float((unsigned)(best2 >> 32)) <= b2;
+        const bool done3 = !PLANE || (best3 != ~0ull && __uint_as_float((unsigned)(best3 >> 32)) <= b2);
+        if (done2 && done3) break;
       }
-      const unsigned long long sm = __ballot(stop);
-      const int first_stop = sm ? (__ffsll((long long)sm) - 1) : 64;
-      if (lane < first_stop) {
-        const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(j - closest);
-        if (c2 && v < best2) best2 = v;
-        if (c3 && v < best3) best3 = v;
+    } else {
+      // literal walks (:312-361 / :402-455) for clouds that are not ring-sorted
+      for (int base = closest + 1; base < nt; base += 64) {
+        const int j = base + lane;
+        bool stop = false;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        int key = 0;
+        if (j < nt) { p = T[j]; key = (int)p.w; stop = (double)key > (double)cid + 2.5; }       // NEARBY_SCAN (:66)
+        const unsigned long long sm = __ballot(stop);
+        const int first_stop = sm ? (__ffsll((long long)sm) - 1) : 64;
+        if (j < nt && lane < first_stop) consider(p, j, key);
+        if (sm) break;
       }
-      if (sm) break;
+      for (int base = closest - 1; base >= 0; base -= 64) {
+        const int j = base - lane;
+        bool stop = false;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        int key = 0;
+        if (j >= 0) { p = T[j]; key = (int)p.w; stop = (double)key < (double)cid - 2.5; }
+        const unsigned long long sm = __ballot(stop);
+        const int first_stop = sm ? (__ffsll((long long)sm) - 1) : 64;
+        if (j >= 0 && lane < first_stop) consider(p, j, key);
+        if (sm) break;
+      }
+      best2 = wave_min_u64(best2);
+      if (PLANE) best3 = wave_min_u64(best3);
     }
-    // downward (:430-455): same-or-higher ring -> min2, lower ring -> min3
-    for (int base = closest - 1; base >= 0; base -= 64) {
-      const int j = base - lane;
-      bool stop = false, c2 = false, c3 = false;
-      float d = 0.f;
-      if (j >= 0) {
-        const float4 p = SL[j];
-        const int key = (int)p.w;
-        if ((double)key < (double)cid - 2.5) stop = true;
-        else { d = walk_dist(p, sel); const bool in = (double)d < 25.0; c2 = in && key >= cid; c3 = in && key < cid; }
-      }
-      const unsigned long long sm = __ballot(stop);
-      const int first_stop = sm ? (__ffsll((long long)sm) - 1) : 64;
-      if (lane < first_stop) {
-        const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | (0x40000000u + (unsigned)(closest - j));
-        if (c2 && v < best2) best2 = v;
-        if (c3 && v < best3) best3 = v;
-      }
-      if (sm) break;
-    }
-    best2 = wave_min_u64(best2);
-    best3 = wave_min_u64(best3);
-    if (best2 != ~0ull && best3 != ~0ull) {                            // :457
-      const unsigned s2 = (unsigned)best2, s3 = (unsigned)best3;
-      min2 = s2 >= 0x40000000u ? closest - (int)(s2 - 0x40000000u) : closest + (int)s2;
-      min3 = s3 >= 0x40000000u ? closest - (int)(s3 - 0x40000000u) : closest + (int)s3;
+    auto decode = [&](unsigned long long v) {
+      const unsigned seq = (unsigned)v;
+      return seq >= 0x40000000u ? closest - (int)(seq - 0x40000000u) : closest + (int)seq;
+    };
+    if (best2 != ~0ull && (!PLANE || best3 != ~0ull)) {                 // :363 / :457
+      min2 = decode(best2);
+      if (PLANE) min3 = decode(best3);
       valid = 1;
     }
   }
   if (lane == 0) {
-    PlaneRec e;
-    e.valid = valid;
-    e.pad[0] = e.pad[1] = e.pad[2] = 0;
-    e.cp[0] = raw.x; e.cp[1] = raw.y; e.cp[2] = raw.z;
-    if (valid) {
-      const float4 pj = SL[closest], pl = SL[min2], pm = SL[min3];
-      e.j[0] = pj.x; e.j[1] = pj.y; e.j[2] = pj.z;
-      e.l[0] = pl.x; e.l[1] = pl.y; e.l[2] = pl.z;
-      e.m[0] = pm.x; e.m[1] = pm.y; e.m[2] = pm.z;
-    } else {
+    if (PLANE) {
+      PlaneRec e;
+      e.valid = valid;
+      e.pad[0] = e.pad[1] = e.pad[2] = 0;
+      e.cp[0] = raw.x; e.cp[1] = raw.y; e.cp[2] = raw.z;               // raw, untransformed point (:460-462)
       for (int k = 0; k < 3; ++k) e.j[k] = e.l[k] = e.m[k] = 0.f;
+      if (valid) {
+        const float4 pj = T[closest], pl = T[min2], pm = T[min3];
+        e.j[0] = pj.x; e.j[1] = pj.y; e.j[2] = pj.z;
+        e.l[0] = pl.x; e.l[1] = pl.y; e.l[2] = pl.z;
+        e.m[0] = pm.x; e.m[1] = pm.y; e.m[2] = pm.z;
+      }
+      a.planes[(long long)b * a.R * 24 + qi] = e;
+    } else {
+      EdgeRec e;
+      e.valid = valid;
+      e.pad[0] = e.pad[1] = 0;
+      e.cp[0] = raw.x; e.cp[1] = raw.y; e.cp[2] = raw.z;               // raw, untransformed point (:365-367)
+      for (int k = 0; k < 3; ++k) e.a[k] = e.b[k] = 0.f;
+      if (valid) {
+        const float4 pa = T[closest], pb = T[min2];
+        e.a[0] = pa.x; e.a[1] = pa.y; e.a[2] = pa.z;
+        e.b[0] = pb.x; e.b[1] = pb.y; e.b[2] = pb.z;
+      }
+      a.edges[(long long)b * a.R * 12 + qi] = e;
     }
-    *rec = e;
   }
 }
 
@@ -563,17 +673,18 @@ __global__ void k_advance(SeqMeta* meta, int B) {
 void launch_advance(SeqMeta* meta, int B, hipStream_t s) { hipLaunchKernelGGL(k_advance, dim3((B + 63) / 64), dim3(64), 0, s, meta, B); }
 
 // -------------------------------------------------------------------------------------------------------
-void launch_nn_search(const OdomArgs& a, int which, int max_queries, int max_targets, hipStream_t s) {
-  int tiles = (max_targets + kNnTile - 1) / kNnTile;
-  if (tiles > 48) tiles = 48;
-  const dim3 grid(tiles, (max_queries + 255) / 256, a.B);
-  hipLaunchKernelGGL(k_nn_search, grid, dim3(256), 0, s, a, which);
+size_t build_grids_lds_bytes(int H, int R) { return sizeof(int) * ((size_t)H + 1024 + 2 * (R + 8) + 4); }
+void launch_build_grids(const OdomArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {   // the surf grid needs > 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)k_build_grids, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_grids_lds_bytes(a.grid_H_surf, kMaxRings));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_build_grids, dim3(2, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
 }
-void launch_walk_corner(const OdomArgs& a, int max_queries, hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_corner, dim3((max_queries + 3) / 4, a.B), dim3(256), 0, s, a);
-}
-void launch_walk_plane(const OdomArgs& a, int max_queries, hipStream_t s) {
-  hipLaunchKernelGGL(k_walk_plane, dim3((max_queries + 3) / 4, a.B), dim3(256), 0, s, a);
+void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_t s) {
+  if (plane) hipLaunchKernelGGL(k_associate<true>, dim3((max_queries + 3) / 4, a.B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_associate<false>, dim3((max_queries + 3) / 4, a.B), dim3(256), 0, s, a);
 }
 void launch_solve(const OdomArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_solve, dim3(a.B), dim3(256), 0, s, a); }
 

@@ -3,9 +3,9 @@
 #include "aloam_device.hpp"
 
 namespace aloam {
-void launch_nn_search(const OdomArgs& a, int which, int max_queries, int max_targets, hipStream_t s);
-void launch_walk_corner(const OdomArgs& a, int max_queries, hipStream_t s);
-void launch_walk_plane(const OdomArgs& a, int max_queries, hipStream_t s);
+size_t build_grids_lds_bytes(int H, int R);
+void launch_build_grids(const OdomArgs& a, hipStream_t s);
+void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_t s);
 void launch_solve(const OdomArgs& a, hipStream_t s);
 void launch_advance(SeqMeta* meta, int B, hipStream_t s);
 }  // namespace aloam

@@ -19,24 +19,31 @@
 namespace aloam {
 
 // -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_find_ends(RegArgs a, const int* __restrict__ n_in) {
+__global__ __launch_bounds__(1024) void k_find_ends(RegArgs a, const int* __restrict__ n_in) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int n = n_in[b];
   const char* in = a.in + (long long)b * a.seq_stride;
   __shared__ int s_first, s_last;
   if (tid == 0) { s_first = 0x7fffffff; s_last = -1; }
   __syncthreads();
-  for (int base = 0; base < n; base += 256) {
-    const int i = base + tid;
-    const bool k = i < n && point_kept(load_point(in, i, a.pt_stride), a.min_range);
-    if (k) atomicMin(&s_first, i);
-    if (__syncthreads_or(k)) break;
+  // 4096 points per iteration: KITTI-like sweeps end with ~18k points inside minimum_range (lowest rings)
+  for (int base = 0; base < n; base += 4096) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + k * 1024 + tid;
+      if (i < n && point_kept(load_point(in, i, a.pt_stride), a.min_range)) { atomicMin(&s_first, i); any = true; }
+    }
+    if (__syncthreads_or(any)) break;
   }
-  for (int base = 0; base < n; base += 256) {
-    const int i = n - 1 - (base + tid);
-    const bool k = i >= 0 && point_kept(load_point(in, i, a.pt_stride), a.min_range);
-    if (k) atomicMax(&s_last, i);
-    if (__syncthreads_or(k)) break;
+  for (int base = 0; base < n; base += 4096) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = n - 1 - (base + k * 1024 + tid);
+      if (i >= 0 && point_kept(load_point(in, i, a.pt_stride), a.min_range)) { atomicMax(&s_last, i); any = true; }
+    }
+    if (__syncthreads_or(any)) break;
   }
   __syncthreads();
   if (tid == 0) {
@@ -145,23 +152,27 @@ __global__ __launch_bounds__(256) void k_classify(RegArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void k_ring_offsets(RegArgs a) {
-  const int b = blockIdx.x, r = threadIdx.x;
+// One wave per ring (16 waves per workgroup): lanes take 64 blocks at a time, exclusive prefix by shuffles.
+__global__ __launch_bounds__(1024) void k_ring_offsets(RegArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ int s_cnt[kMaxRings];
   const int n = a.meta[b].n_in < a.cap ? a.meta[b].n_in : a.cap;
   const int nb = (n + kBlockPts - 1) / kBlockPts;
-  if (r < a.R) {
-    int run = 0;
-    for (int blk = 0; blk < nb; ++blk) {
+  for (int r = wave; r < a.R; r += 16) {
+    int carry = 0;
+    for (int base = 0; base < nb; base += 64) {
+      const int blk = base + lane;
       const long long o = ((long long)b * a.NB + blk) * a.R + r;
-      const int h = a.hist[o];
-      a.blockoff[o] = run;
-      run += h;
+      const int h = blk < nb ? a.hist[o] : 0;
+      int incl = h;
+      for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+      if (blk < nb) a.blockoff[o] = carry + incl - h;
+      carry += __shfl(incl, 63, 64);
     }
-    s_cnt[r] = run;
+    if (lane == 0) s_cnt[r] = carry;
   }
   __syncthreads();
-  if (r == 0) {
+  if (tid == 0) {
     int run = 0;
     for (int q = 0; q < a.R; ++q) { a.ringstart[b * (a.R + 1) + q] = run; run += s_cnt[q]; }
     a.ringstart[b * (a.R + 1) + a.R] = run;
@@ -562,9 +573,9 @@ size_t ring_features_lds_bytes(int npad) {
   return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 4) * sizeof(int);
 }
 
-void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s) { hipLaunchKernelGGL(k_find_ends, dim3(a.B), dim3(256), 0, s, a, d_nin); }
+void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s) { hipLaunchKernelGGL(k_find_ends, dim3(a.B), dim3(1024), 0, s, a, d_nin); }
 void launch_classify(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_classify, dim3(a.NB, a.B), dim3(256), 0, s, a); }
-void launch_ring_offsets(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ring_offsets, dim3(a.B), dim3(128), 0, s, a); }
+void launch_ring_offsets(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ring_offsets, dim3(a.B), dim3(1024), 0, s, a); }
 void launch_scatter(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_scatter, dim3(a.NB, a.B), dim3(256), 0, s, a); }
 void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s) {
   const size_t lds = ring_features_lds_bytes(npad);
