@@ -1,0 +1,22 @@
+#!/bin/bash
+# tools/gpu_round.sh <tag> — one GPU-box visit: parity tests, default bench (with cpu_baseline), rocprofv3 kernel
+# stats of the same bench command, and two separate --pmc passes (FETCH_SIZE / WRITE_SIZE) for the roofline traffic.
+# Outputs land in gpurun_out/<tag>/ ; copy the summaries to profiles/ afterwards.
+TAG=${1:-run}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
+python bench.py > $O/bench.log 2>&1; tail -c 2500 $O/bench.log
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $BENCH > $O/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex aloam --output-format csv -d /tmp/pmc_fetch -o p -- $BENCH --steps 4 --warmup 1 > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex aloam --output-format csv -d /tmp/pmc_write -o p -- $BENCH --steps 4 --warmup 1 > $O/pmc_write.log 2>&1
+cd $R
+python tools/rocprof_summary.py $O/stats/s_results.db $O/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline" > /dev/null
+python tools/pmc_summary.py /tmp/pmc_fetch $O/pmc_fetch.md > /dev/null
+python tools/pmc_summary.py /tmp/pmc_write $O/pmc_write.md > /dev/null
+rm -rf $O/stats
+cat $O/kernel_stats.md $O/pmc_fetch.md $O/pmc_write.md

@@ -1,0 +1,29 @@
+"""Summarise rocprofv3 --pmc CSV output (counter_collection + kernel_trace) for the aloam:: kernels.
+    python tools/pmc_summary.py <dir-with-csvs> <out.md>"""
+import glob, sys
+import pandas as pd
+
+
+def main(d, out):
+    cc = pd.concat([pd.read_csv(f) for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)])
+    cc = cc[cc.Kernel_Name.str.contains("aloam::")]
+    cc["kernel"] = cc.Kernel_Name.str.extract(r"aloam::(\w+(?:<\w+>)?)")
+    piv = cc.pivot_table(index="kernel", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
+    cnt = cc.groupby("kernel").Dispatch_Id.nunique().rename("dispatches")
+    piv = piv.join(cnt)
+    kts = glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True)
+    if kts:
+        kt = pd.concat([pd.read_csv(f) for f in kts])
+        kt = kt[kt.Kernel_Name.str.contains("aloam::")]
+        kt["kernel"] = kt.Kernel_Name.str.extract(r"aloam::(\w+(?:<\w+>)?)")
+        kt["us"] = (kt.End_Timestamp - kt.Start_Timestamp) / 1e3
+        piv = piv.join(kt.groupby("kernel").us.mean().rename("avg_us"))
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --pmc summary (mean per dispatch, aloam:: kernels only)\n\n```\n")
+        f.write(piv.to_string(float_format=lambda v: f"{v:,.0f}"))
+        f.write("\n```\n")
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
