@@ -238,8 +238,14 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int whi
 // downward from closest-1); "first strictly smaller wins" is the lexicographic (distance, visit order) minimum.
 template <bool PLANE>
 __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs by linear id and every XCD has its
+  // own 4 MiB L2.  The grids of one sequence (~1.5 MB) are shared by all workgroups of that sequence, so the linear id
+  // is re-mapped such that XCD x works through sequences x, x+8, x+16, ...: each L2 holds a few sequences' grids
+  // instead of thrashing on all of them.  (Pure placement: any mapping gives the same result.)
+  const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int b = (slot / (int)gridDim.x) * 8 + xcd, lane = threadIdx.x & 63;
+  if (b >= a.B) return;
+  const int qi = (slot % (int)gridDim.x) * 4 + (threadIdx.x >> 6);
   const SeqMeta m = a.meta[b];
   const int nq = PLANE ? m.n_flat : m.n_sharp;
   if (qi >= nq) return;
@@ -683,8 +689,9 @@ void launch_build_grids(const OdomArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_build_grids, dim3(2, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
 }
 void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_t s) {
-  if (plane) hipLaunchKernelGGL(k_associate<true>, dim3((max_queries + 3) / 4, a.B), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_associate<false>, dim3((max_queries + 3) / 4, a.B), dim3(256), 0, s, a);
+  const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
+  if (plane) hipLaunchKernelGGL(k_associate<true>, dim3((max_queries + 3) / 4, by), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_associate<false>, dim3((max_queries + 3) / 4, by), dim3(256), 0, s, a);
 }
 void launch_solve(const OdomArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_solve, dim3(a.B), dim3(256), 0, s, a); }
 

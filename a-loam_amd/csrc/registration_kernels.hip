@@ -297,6 +297,10 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   int* s_scan = reinterpret_cast<int*>(smem + ((A_BYTES + 15) & ~15) + 2 * FLAG_BYTES);
   float (*s_red)[4] = reinterpret_cast<float (*)[4]>(s_scan + 256);
   int* s_misc = reinterpret_cast<int*>(s_scan + 256 + 24);
+  // picks of the 6 sectors (local indices), staged in LDS so that the serial picking loop issues no global store:
+  // [j][0..1] sharp, [j][2..21] less sharp, [j][22..25] flat
+  constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
+  volatile short* s_pick = reinterpret_cast<volatile short*>(s_misc + 8);
 
   const float4* cloud = a.cloud + (long long)b * a.cap + start;
   for (int i = tid; i < n; i += 256) {
@@ -348,10 +352,10 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   bitonic_sort_u64(keys, npad, tid);
 
   // ---- greedy picking, sectors in order (suppression marks spill across sector borders) — one wave
+  int* sharp_idx = a.sharp_idx + ((long long)(b * a.R + r) * kSectors) * kSharpPerSector;
+  int* less_idx = a.less_sharp_idx + ((long long)(b * a.R + r) * kSectors) * kLessSharpPerSector;
+  int* flat_idx = a.flat_idx + ((long long)(b * a.R + r) * kSectors) * kFlatPerSector;
   if (wave == 0) {
-    int* sharp_idx = a.sharp_idx + ((long long)(b * a.R + r) * kSectors) * kSharpPerSector;
-    int* less_idx = a.less_sharp_idx + ((long long)(b * a.R + r) * kSectors) * kLessSharpPerSector;
-    int* flat_idx = a.flat_idx + ((long long)(b * a.R + r) * kSectors) * kFlatPerSector;
     for (int j = 0; j < kSectors; ++j) {
       const int sp = (L * j) / 6, ep = (L * (j + 1)) / 6 - 1;
       // corners: largest curvature first (:291-344)
@@ -374,11 +378,10 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
           if (count > kLessSharpPerSector) { done = true; break; }           // 21st: break before marking (:312-315)
           if (lane == 0) {
             label[kf] = count <= kSharpPerSector ? 2 : 1;
-            if (count <= kSharpPerSector) sharp_idx[j * kSharpPerSector + count - 1] = start + kf;
-            less_idx[j * kLessSharpPerSector + count - 1] = start + kf;
+            s_pick[j * kSlots + kSharpPerSector + count - 1] = (short)kf;
           }
           suppress_neighbours(flags, kf, lane);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();     // single wave, volatile LDS: program order is enough, no memory fence
           cand = cand && lane > f;
         }
       }
@@ -399,22 +402,33 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
           if (!mask) break;
           const int f = __ffsll((long long)mask) - 1;
           const int kf = __shfl(kpt, f, 64);
-          if (lane == 0) { label[kf] = -1; flat_idx[j * kFlatPerSector + count] = start + kf; }
+          if (lane == 0) { label[kf] = -1; s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + count] = (short)kf; }
           ++count;
           if (count >= kFlatPerSector) { done = true; break; }                // 4th: break before marking (:359-362)
           suppress_neighbours(flags, kf, lane);
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
           cand = cand && lane > f;
         }
       }
       if (lane == 0) {
-        pick_cnt[j * 3 + 0] = ncorner < kSharpPerSector ? ncorner : kSharpPerSector;
-        pick_cnt[j * 3 + 1] = ncorner;
-        pick_cnt[j * 3 + 2] = count;
+        s_misc[1 + j] = ncorner | (count << 8);
       }
     }
   }
   __syncthreads();
+  // picks out: sharp = the first two less-sharp picks (:301-311)
+  if (tid < kSectors * kSlots) {
+    const int j = tid / kSlots, slot = tid % kSlots;
+    const int ncorner = s_misc[1 + j] & 0xff, nflat = s_misc[1 + j] >> 8;
+    if (slot < kSharpPerSector) { if (slot < ncorner) sharp_idx[j * kSharpPerSector + slot] = start + s_pick[j * kSlots + kSharpPerSector + slot]; }
+    else if (slot < kSharpPerSector + kLessSharpPerSector) { const int q = slot - kSharpPerSector; if (q < ncorner) less_idx[j * kLessSharpPerSector + q] = start + s_pick[j * kSlots + slot]; }
+    else { const int q = slot - kSharpPerSector - kLessSharpPerSector; if (q < nflat) flat_idx[j * kFlatPerSector + q] = start + s_pick[j * kSlots + slot]; }
+    if (slot == 0) {
+      pick_cnt[j * 3 + 0] = ncorner < kSharpPerSector ? ncorner : kSharpPerSector;
+      pick_cnt[j * 3 + 1] = ncorner;
+      pick_cnt[j * 3 + 2] = nflat;
+    }
+  }
 
   // ---- labels out (parity / debugging) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
   for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
@@ -570,7 +584,7 @@ size_t ring_features_lds_bytes(int npad) {
   const int maxn = npad + 11;
   const int a_bytes = (12 * maxn > 8 * npad ? 12 * maxn : 8 * npad);
   const int flag_bytes = (maxn + 15) & ~15;
-  return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 4) * sizeof(int);
+  return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 8) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
 }
 
 void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s) { hipLaunchKernelGGL(k_find_ends, dim3(a.B), dim3(1024), 0, s, a, d_nin); }

@@ -1,0 +1,42 @@
+"""Regenerates tests/golden/ref_*.npz from oracle/_ref — outputs of the REFERENCE'S OWN translation units
+(/root/reference/src/scanRegistration.cpp, src/laserOdometry.cpp + src/lidarFactor.hpp, compiled in place against the
+stand-in third-party headers of oracle/ref_shim/) on small seeded synthetic sweeps.
+
+Needs /root/reference (this container only); the resulting fixtures travel with the repo and pin both the oracle and
+the HIP path wherever the tests run.
+    python tools/make_ref_golden.py
+"""
+import importlib, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import ref_py
+syn = importlib.import_module("a-loam_amd.synthetic")
+
+CASES = [("ref_vlp16_c600_seed11", "VLP-16", 4, 11, {"columns": 600}), ("ref_hdl64_c256_seed12", "HDL-64", 4, 12, {"columns": 256})]
+
+
+def main():
+    assert ref_py.build(), "oracle/_ref could not be built (is /root/reference present?)"
+    for tag, name, frames, seed, kw in CASES:
+        scans, R, t, model = syn.make_sequence(name, frames, seed=seed, **kw)
+        xs = [s.numpy() for s in scans]
+        reg = ref_py.scan_registration(xs, model.n_scans, model.min_range)
+        odo = ref_py.laser_odometry(reg)
+        out = {"R": R.numpy(), "t": t.numpy(), "n_scans": model.n_scans, "min_range": model.min_range, "frames": frames}
+        for k in range(frames):
+            out[f"scan{k}"] = xs[k]
+            for key in ("sharp", "less_sharp", "flat", "less_flat", "curvature", "label"):
+                out[f"{key}{k}"] = reg[k][key]
+            out[f"cloud_intensity{k}"] = reg[k]["cloud"][:, 3].copy()      # xyz of the ring-ordered cloud are a permutation of the input
+            out[f"cloud_xyz_sum{k}"] = reg[k]["cloud"][:, :3].astype(np.float64).sum(0)
+            for key in ("q_lc", "t_lc", "q_w", "t_w"):
+                out[f"{key}{k}"] = odo[k][key]
+            out[f"corr{k}"] = np.array([odo[k]["corner_corr"], odo[k]["plane_corr"]])
+        path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()
