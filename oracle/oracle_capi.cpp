@@ -199,3 +199,62 @@ float orc_atan2f_port(float y, float x) { return orc::atan2f_port(y, x); }
 void orc_quat_plus(const double q[4], const double delta[3], double out[4]) { orc::quat_plus(q, delta, out); }
 
 }  // extern "C"
+
+// ---- scan-to-map refinement -------------------------------------------------------------------------------------
+extern "C" {
+int orc_map_config(orc_ctx* ctx, float line_res, float plane_res) { ctx->map.line_res = line_res; ctx->map.plane_res = plane_res; return 0; }
+int orc_mapping_step(orc_ctx* ctx, const double q_wodom[4], const double t_wodom[3], const float* corner_last, int n_corner, const float* surf_last,
+                     int n_surf, const float* full_res, int n_full) {
+  return orc::mapping_step(ctx->cfg, &ctx->map, q_wodom, t_wodom, to_vec(corner_last, n_corner), to_vec(surf_last, n_surf), to_vec(full_res, n_full));
+}
+int orc_map_get_pose(const orc_ctx* ctx, double q_w_curr[4], double t_w_curr[3], double q_wmap_wodom[4], double t_wmap_wodom[3]) {
+  const orc::MapState& m = ctx->map;
+  for (int k = 0; k < 4; ++k) q_w_curr[k] = m.parameters[k];
+  for (int k = 0; k < 3; ++k) t_w_curr[k] = m.parameters[4 + k];
+  q_wmap_wodom[0] = m.q_wmap_wodom.x; q_wmap_wodom[1] = m.q_wmap_wodom.y; q_wmap_wodom[2] = m.q_wmap_wodom.z; q_wmap_wodom[3] = m.q_wmap_wodom.w;
+  t_wmap_wodom[0] = m.t_wmap_wodom.x; t_wmap_wodom[1] = m.t_wmap_wodom.y; t_wmap_wodom[2] = m.t_wmap_wodom.z;
+  return 0;
+}
+int orc_map_get_info(const orc_ctx* ctx, int out[16]) {
+  const orc::MapState& m = ctx->map;
+  const int v[16] = {m.cenW, m.cenH, m.cenD, m.frame_count, m.from_map_corner, m.from_map_surf, (int)m.corner_stack.size(), (int)m.surf_stack.size(),
+                     m.corner_num[0], m.corner_num[1], m.surf_num[0], m.surf_num[1], m.lm[0].iterations, m.lm[1].iterations, m.lm[0].termination, m.lm[1].termination};
+  std::memcpy(out, v, sizeof(v));
+  return 0;
+}
+/* which: 0 corner cube, 1 surf cube (cube = index into the 21 x 21 x 11 window), 2 registered cloud, 3 corner stack, 4 surf stack */
+static const std::vector<P4>* map_pick(const orc_ctx* c, int which, int cube) {
+  switch (which) {
+    case 0: return (cube >= 0 && cube < orc::MapState::NUM) ? &c->map.corner[cube] : nullptr;
+    case 1: return (cube >= 0 && cube < orc::MapState::NUM) ? &c->map.surf[cube] : nullptr;
+    case 2: return &c->map.registered;
+    case 3: return &c->map.corner_stack;
+    case 4: return &c->map.surf_stack;
+    default: return nullptr;
+  }
+}
+int orc_map_cloud_size(const orc_ctx* ctx, int which, int cube) { const std::vector<P4>* v = map_pick(ctx, which, cube); return v ? (int)v->size() : -1; }
+int orc_map_get_cloud(const orc_ctx* ctx, int which, int cube, float* out, int cap) {
+  const std::vector<P4>* v = map_pick(ctx, which, cube);
+  if (!v) return -1;
+  copy_cloud(*v, out, cap);
+  return (int)v->size();
+}
+int orc_map_cube_counts(const orc_ctx* ctx, int cls, int* out) {     /* out[4851] */
+  const auto& arr = cls == 0 ? ctx->map.corner : ctx->map.surf;
+  for (int i = 0; i < orc::MapState::NUM; ++i) out[i] = (int)arr[i].size();
+  return orc::MapState::NUM;
+}
+int orc_knn_search(const float* target_xyzi, int n_target, const float* query_xyzi, int n_query, int k, int brute, int* idx, float* d2) {
+  orc::KnnIndex t;
+  t.build(to_vec(target_xyzi, n_target));
+  for (int i = 0; i < n_query; ++i) {
+    P4 q; std::memcpy(&q, query_xyzi + 4 * (size_t)i, sizeof(P4));
+    const int n = t.query(q, k, brute != 0, idx + (size_t)i * k, d2 + (size_t)i * k);
+    for (int j = n; j < k; ++j) { idx[(size_t)i * k + j] = -1; d2[(size_t)i * k + j] = 0.f; }
+  }
+  return 0;
+}
+void orc_sym_eigen3(const double A[9], double vals[3], double vecs[9]) { orc::sym_eigen3(A, vals, vecs); }
+void orc_lstsq_5x3(const double A[15], const double b[5], double x[3]) { orc::lstsq_5x3(A, b, x); }
+}

@@ -38,6 +38,8 @@ struct NnIndex {
 struct EdgeRec { V3d cp, a, b; int query; };          // LidarEdgeFactor ctor args  (lidarFactor.hpp:14-16)
 struct PlaneRec { V3d cp, j, l, m; int query; };       // LidarPlaneFactor ctor args (lidarFactor.hpp:59-62)
 
+struct NormRec { V3d cp, n; double d; int query; };   // LidarPlaneNormFactor ctor args (lidarFactor.hpp:109-111)
+
 struct LmSummary { int iterations = 0, successful = 0, termination = 0; double initial_cost = 0, final_cost = 0; };
 
 void factor_eval_edge(const EdgeRec& e, const double q[4], const double t[3], bool analytic, double r[3], double J[18]);
@@ -45,7 +47,8 @@ void factor_eval_plane(const PlaneRec& p, const double q[4], const double t[3], 
 double robust_cost(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec>& planes, const double q[4], const double t[3]);
 void quat_plus(const double q[4], const double delta[3], double out[4]);
 LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec>& planes, double q[4], double t[3],
-                   int max_iterations, bool analytic, bool apply_converged_step);
+                   int max_iterations, bool analytic, bool apply_converged_step, const std::vector<NormRec>* norms = nullptr);
+void factor_eval_norm(const NormRec& p, const double q[4], const double t[3], bool analytic, double r[1], double J[6]);
 
 struct OdomState {
   double para_q[4] = {0, 0, 0, 1};        // laserOdometry.cpp:97
@@ -63,11 +66,43 @@ struct OdomState {
 int odometry_step(const orc_config& cfg, const std::vector<P4>& sharp, const std::vector<P4>& less_sharp,
                   const std::vector<P4>& flat, const std::vector<P4>& less_flat, OdomState* st, std::string* err);
 
+// ---- scan-to-map refinement (reference src/laserMapping.cpp) -----------------------------------------------
+struct KnnIndex {                       // exact k-NN, ascending (f32 distance, index): pcl::KdTreeFLANN::nearestKSearch stand-in
+  NnIndex tree;
+  void build(const std::vector<P4>& cloud) { tree.build(cloud); }
+  int query(const P4& q, int k, bool brute, int* idx, float* d2) const;
+};
+
+struct MapState {
+  static constexpr int W = 21, H = 21, D = 11, NUM = W * H * D;       // laserMapping.cpp:75-80
+  int cenW = 10, cenH = 10, cenD = 5;                                 // :72-74
+  float line_res = 0.4f, plane_res = 0.8f;                            // :900-901
+  std::vector<std::vector<P4>> corner, surf;                          // laserCloudCornerArray / SurfArray (:102-103)
+  double parameters[7] = {0, 0, 0, 1, 0, 0, 0};                       // q_w_curr (xyzw), t_w_curr (:109-111)
+  Quatd q_wmap_wodom{0, 0, 0, 1};                                     // :115-116
+  V3d t_wmap_wodom{0, 0, 0};
+  std::vector<P4> registered;                                         // /velodyne_cloud_registered payload (:836-846)
+  std::vector<P4> corner_stack, surf_stack;                           // down-sampled inputs of the last frame (:542-550)
+  std::vector<int> valid;                                             // laserCloudValidInd of the last frame
+  std::vector<EdgeRec> edges;                                         // factors of the last iteration
+  std::vector<NormRec> norms;
+  int frame_count = 0;
+  int corner_num[2] = {0, 0}, surf_num[2] = {0, 0};                   // factors per iteration
+  int from_map_corner = 0, from_map_surf = 0;
+  LmSummary lm[2];
+  MapState() : corner(NUM), surf(NUM) {}
+};
+int mapping_step(const orc_config& cfg, MapState* st, const double q_wodom[4], const double t_wodom[3], const std::vector<P4>& corner_last,
+                 const std::vector<P4>& surf_last, const std::vector<P4>& full_res);
+void sym_eigen3(const double A[9], double vals[3], double vecs[9]);           // SelfAdjointEigenSolver<Matrix3d> stand-in (ascending)
+void lstsq_5x3(const double A[15], const double b[5], double x[3]);           // colPivHouseholderQr().solve stand-in
+
 }  // namespace orc
 
 struct orc_ctx {
   orc_config cfg;
   orc::RegistrationResult reg;
   orc::OdomState odom;
+  orc::MapState map;
   std::string err;
 };

@@ -73,6 +73,16 @@ def lib():
         L.orc_lm_solve.argtypes = [C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, ip]
         L.orc_atan2f_port.argtypes = [C.c_float, C.c_float]; L.orc_atan2f_port.restype = C.c_float
         L.orc_quat_plus.argtypes = [vp, vp, vp]
+        L.orc_map_config.argtypes = [vp, C.c_float, C.c_float]
+        L.orc_mapping_step.argtypes = [vp, vp, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int]
+        L.orc_map_get_pose.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_map_get_info.argtypes = [vp, vp]
+        L.orc_map_cloud_size.argtypes = [vp, C.c_int, C.c_int]
+        L.orc_map_get_cloud.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
+        L.orc_map_cube_counts.argtypes = [vp, C.c_int, vp]
+        L.orc_knn_search.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.orc_sym_eigen3.argtypes = [vp, vp, vp]; L.orc_sym_eigen3.restype = None
+        L.orc_lstsq_5x3.argtypes = [vp, vp, vp]; L.orc_lstsq_5x3.restype = None
         _lib = L
     return _lib
 
@@ -180,6 +190,69 @@ class Oracle:
         return e[:ne.value].copy(), p[:npl.value].copy(), eq[:ne.value].copy(), pq[:npl.value].copy()
 
 
+MAP_CORNER_CUBE, MAP_SURF_CUBE, MAP_REGISTERED, MAP_CORNER_STACK, MAP_SURF_STACK = range(5)
+MAP_INFO_KEYS = ("cenW", "cenH", "cenD", "frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack",
+                 "corner_num0", "corner_num1", "surf_num0", "surf_num1", "lm_iterations0", "lm_iterations1", "termination0", "termination1")
+
+
+def _map_methods():
+    def map_config(self, line_res, plane_res):
+        lib().orc_map_config(self.h, float(line_res), float(plane_res))
+
+    def mapping_step(self, q_wodom, t_wodom, corner_last, surf_last, full_res):
+        """One pass of process() (laserMapping.cpp:231-893) on what the node receives for one frame."""
+        q, t = _f64(q_wodom), _f64(t_wodom)
+        c, s, f = _f32(corner_last), _f32(surf_last), _f32(full_res)
+        rc = lib().orc_mapping_step(self.h, _p(q), _p(t), _p(c), len(c), _p(s), len(s), _p(f), len(f))
+        if rc:
+            raise RuntimeError(lib().orc_last_error(self.h).decode())
+        return self.map_pose()
+
+    def map_pose(self):
+        qw, tw, qm, tm = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        lib().orc_map_get_pose(self.h, _p(qw), _p(tw), _p(qm), _p(tm))
+        return {"q_w": qw, "t_w": tw, "q_wmap_wodom": qm, "t_wmap_wodom": tm}
+
+    def map_info(self):
+        v = np.zeros(16, np.int32)
+        lib().orc_map_get_info(self.h, _p(v))
+        return dict(zip(MAP_INFO_KEYS, (int(x) for x in v)))
+
+    def map_cloud(self, which, cube=0):
+        n = lib().orc_map_cloud_size(self.h, which, cube)
+        out = np.zeros((max(n, 0), 4), np.float32)
+        if n > 0:
+            lib().orc_map_get_cloud(self.h, which, cube, _p(out), n)
+        return out
+
+    def map_cubes(self, cls):
+        """{cube index: (n, 4) points} of the non-empty cubes of class 0 (corner) / 1 (surf)."""
+        cnt = np.zeros(21 * 21 * 11, np.int32)
+        lib().orc_map_cube_counts(self.h, cls, _p(cnt))
+        return {int(i): self.map_cloud(cls, int(i)) for i in np.nonzero(cnt)[0]}
+
+    return dict(map_config=map_config, mapping_step=mapping_step, map_pose=map_pose, map_info=map_info, map_cloud=map_cloud, map_cubes=map_cubes)
+
+
+def knn_search(target, query, k=5, brute=False):
+    t, q = _f32(target), _f32(query)
+    idx = np.zeros((len(q), k), np.int32); d2 = np.zeros((len(q), k), np.float32)
+    lib().orc_knn_search(_p(t), len(t), _p(q), len(q), k, int(brute), _p(idx), _p(d2))
+    return idx, d2
+
+
+def sym_eigen3(A):
+    A = _f64(A); vals = np.zeros(3); vecs = np.zeros((3, 3))
+    lib().orc_sym_eigen3(_p(A), _p(vals), _p(vecs))
+    return vals, vecs
+
+
+def lstsq_5x3(A, b):
+    A, b = _f64(A), _f64(b); x = np.zeros(3)
+    lib().orc_lstsq_5x3(_p(A), _p(b), _p(x))
+    return x
+
+
 def voxel_filter(xyzi, leaf, canonical=True):
     a = _f32(xyzi)
     out = np.zeros_like(a)
@@ -225,3 +298,7 @@ def quat_plus(q, delta):
     q, d, out = _f64(q), _f64(delta), np.zeros(4)
     lib().orc_quat_plus(_p(q), _p(d), _p(out))
     return out
+
+
+for _name, _fn in _map_methods().items():
+    setattr(Oracle, _name, _fn)

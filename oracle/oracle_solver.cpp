@@ -148,6 +148,44 @@ void factor_eval_plane(const PlaneRec& p, const double q[4], const double t[3], 
   J[3] = n.x; J[4] = n.y; J[5] = n.z;
 }
 
+// LidarPlaneNormFactor (lidarFactor.hpp:106-138): r = n . (q * cp + t) + d.  Functor instantiated on Jet<7> like
+// ceres::AutoDiffCostFunction<LidarPlaneNormFactor, 1, 4, 3>, or the closed form the HIP path uses.
+template <typename T>
+static void norm_functor(const NormRec& p, const T* q, const T* t, T* residual) {
+  const Quat<T> q_w_curr{q[0], q[1], q[2], q[3]};
+  const V3<T> t_w_curr{t[0], t[1], t[2]};
+  const V3<T> cp{T(p.cp.x), T(p.cp.y), T(p.cp.z)};
+  const V3<T> point_w = rotate(q_w_curr, cp) + t_w_curr;
+  const V3<T> norm{T(p.n.x), T(p.n.y), T(p.n.z)};
+  residual[0] = dot(norm, point_w) + T(p.d);
+}
+void factor_eval_norm(const NormRec& p, const double q[4], const double t[3], bool analytic, double r[1], double J[6]) {
+  if (!analytic) {
+    typedef Jet<7> J7;
+    J7 jq[4], jt[3], jr[1];
+    for (int k = 0; k < 4; ++k) jq[k] = J7(q[k], k);
+    for (int k = 0; k < 3; ++k) jt[k] = J7(t[k], 4 + k);
+    norm_functor<J7>(p, jq, jt, jr);
+    double P[12];
+    quat_plus_jacobian(q, P);
+    r[0] = jr[0].a;
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0.0;
+      for (int k = 0; k < 4; ++k) acc += jr[0].v[k] * P[k * 3 + c];
+      J[c] = acc;
+      J[3 + c] = jr[0].v[4 + c];
+    }
+    return;
+  }
+  V3d lp, rcp;
+  closed_form_lp(p.cp, q, t, &lp, &rcp);
+  r[0] = dot(p.n, lp) + p.d;
+  J[0] = 2.0 * (p.n.z * rcp.y - p.n.y * rcp.z);
+  J[1] = 2.0 * (p.n.x * rcp.z - p.n.z * rcp.x);
+  J[2] = 2.0 * (p.n.y * rcp.x - p.n.x * rcp.y);
+  J[3] = p.n.x; J[4] = p.n.y; J[5] = p.n.z;
+}
+
 // HuberLoss(a = 0.1) : rho, rho'  (Ceres loss_function.cc)
 static inline void huber(double s, double* rho0, double* rho1) {
   const double a = 0.1, b = a * a;
@@ -166,7 +204,8 @@ struct Problem {
   const std::vector<EdgeRec>& edges;
   const std::vector<PlaneRec>& planes;
   bool analytic;
-  int rows() const { return 3 * (int)edges.size() + (int)planes.size(); }
+  const std::vector<NormRec>* norms = nullptr;     // LidarPlaneNormFactor blocks (mapping only)
+  int rows() const { return 3 * (int)edges.size() + (int)planes.size() + (norms ? (int)norms->size() : 0); }
   // cost = 1/2 sum rho(|r_block|^2); residuals / Jacobian rows scaled by sqrt(rho') (Corrector with rho'' <= 0).
   double evaluate(const double q[4], const double t[3], std::vector<double>* res, std::vector<double>* jac) const {
     double cost = 0.0;
@@ -193,6 +232,17 @@ struct Problem {
       const double s = r[0] * r[0];
       double rho0, rho1;
       huber(s, &rho0, &rho1);
+      cost += 0.5 * rho0;
+      const double sc = std::sqrt(rho1);
+      if (res) (*res)[row] = sc * r[0];
+      if (jac) for (int c = 0; c < 6; ++c) (*jac)[(size_t)row * 6 + c] = sc * J[c];
+      row += 1;
+    }
+    if (norms) for (const NormRec& p : *norms) {
+      double r[1], J[6];
+      factor_eval_norm(p, q, t, analytic, r, J);
+      double rho0, rho1;
+      huber(r[0] * r[0], &rho0, &rho1);
       cost += 0.5 * rho0;
       const double sc = std::sqrt(rho1);
       if (res) (*res)[row] = sc * r[0];
@@ -250,9 +300,9 @@ double robust_cost(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
 // ceres::Solve with TRUST_REGION / LEVENBERG_MARQUARDT / DENSE_QR, jacobi_scaling on, monotonic steps,
 // defaults otherwise, max_num_iterations as given.
 LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec>& planes, double q[4], double t[3],
-                   int max_iterations, bool analytic, bool apply_converged_step) {
+                   int max_iterations, bool analytic, bool apply_converged_step, const std::vector<NormRec>* norms) {
   LmSummary sm;
-  Problem pb{edges, planes, analytic};
+  Problem pb{edges, planes, analytic, norms};
   const int m = pb.rows();
   if (m == 0) { sm.termination = 4; return sm; }
 

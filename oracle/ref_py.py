@@ -19,7 +19,7 @@ REFERENCE_ROOT = os.environ.get("ALOAM_REFERENCE_ROOT", "/root/reference")
 
 
 def available() -> bool:
-    return all(os.path.exists(os.path.join(REF_DIR, n)) for n in ("ref_scan_registration", "ref_laser_odometry"))
+    return all(os.path.exists(os.path.join(REF_DIR, n)) for n in ("ref_scan_registration", "ref_laser_odometry", "ref_laser_mapping"))
 
 
 def build() -> bool:
@@ -107,5 +107,37 @@ def laser_odometry(frames):
             cc, pc = rd.i32(), rd.i32()
             out.append({"q_w": v[0:4], "t_w": v[4:7], "q_lc": v[7:11], "t_lc": v[11:14], "corner_corr": cc, "plane_corr": pc,
                         "corner_last": rd.cloud(), "surf_last": rd.cloud()})
+        assert rd.done()
+        return out
+
+
+def laser_mapping(frames, line_res, plane_res, dump_map=True):
+    """frames: list of dicts with q_w / t_w (odometry pose), corner_last, surf_last, cloud (full resolution) -> list of dicts
+    (q_w, t_w = refined pose, q_wmap_wodom, t_wmap_wodom, registered, cen, corner_map {cube: pts}, surf_map {cube: pts})."""
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<i", len(frames)))
+            for fr in frames:
+                f.write(np.concatenate([np.asarray(fr["q_w"], np.float64), np.asarray(fr["t_w"], np.float64)]).tobytes())
+                for k in ("corner_last", "surf_last", "cloud"):
+                    _write_cloud(f, fr[k])
+        r = subprocess.run([os.path.join(REF_DIR, "ref_laser_mapping"), repr(float(line_res)), repr(float(plane_res)), fin, fout],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"ref_laser_mapping failed ({r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
+        rd = _Reader(fout)
+        out = []
+        for _ in frames:
+            v = rd.f64(14)
+            fr = {"q_w": v[0:4], "t_w": v[4:7], "q_wmap_wodom": v[7:11], "t_wmap_wodom": v[11:14], "registered": rd.cloud(),
+                  "cen": (rd.i32(), rd.i32(), rd.i32())}
+            for name in ("corner_map", "surf_map"):
+                m = {}
+                for _c in range(rd.i32()):
+                    cube = rd.i32()
+                    m[cube] = rd.cloud()
+                fr[name] = m if dump_map else {c: len(p) for c, p in m.items()}
+            out.append(fr)
         assert rd.done()
         return out

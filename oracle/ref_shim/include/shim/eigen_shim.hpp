@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstddef>
 #include <limits>
+#include <utility>
 
 namespace Eigen {
 
@@ -195,9 +196,9 @@ class SelfAdjointEigenSolver<Matrix3d> {
   explicit SelfAdjointEigenSolver(const Matrix3d& A0) {
     double a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a[i][j] = 0.5 * (A0(i, j) + A0(j, i));
-    for (int sweep = 0; sweep < 64; ++sweep) {
-      const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-      if (off == 0.0) break;
+    for (int sweep = 0; sweep < 50; ++sweep) {
+      const double off = std::fabs(a[0][1]) + std::fabs(a[0][2]) + std::fabs(a[1][2]);
+      if (off <= 1e-22 * (std::fabs(a[0][0]) + std::fabs(a[1][1]) + std::fabs(a[2][2]))) break;
       for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
         if (a[p][q] == 0.0) continue;
         const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
@@ -205,6 +206,7 @@ class SelfAdjointEigenSolver<Matrix3d> {
         const double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
         for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = cs * akp - sn * akq; a[k][q] = sn * akp + cs * akq; }
         for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = cs * apk - sn * aqk; a[q][k] = sn * apk + cs * aqk; }
+        a[p][q] = 0.0; a[q][p] = 0.0;
         for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = cs * vkp - sn * vkq; v[k][q] = sn * vkp + cs * vkq; }
       }
     }

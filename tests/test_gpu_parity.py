@@ -176,7 +176,7 @@ def test_single_long_ring_uses_large_lds_class(O, binding):
     gpu.close()
 
 
-@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("ref_")))
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("ref")))
 def test_gpu_reproduces_committed_goldens(binding, path):
     g = np.load(path)
     gpu = binding.Aloam(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), max_points=40000)

@@ -299,7 +299,7 @@ def test_kdtree_and_brute_force_give_identical_odometry(O, sequence):
 
 
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("ref_")))
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if not os.path.basename(p).startswith("ref")))
 def test_oracle_reproduces_committed_goldens(O, path):
     g = np.load(path)
     orc = O.Oracle(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]))

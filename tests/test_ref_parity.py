@@ -143,3 +143,85 @@ def test_gpu_vs_reference_code(binding, path):
         worst_r = max(worst_r, quat_angle(p["q_lc"], g[f"q_lc{k}"]), quat_angle(p["q_w"], g[f"q_w{k}"]))
     assert worst_t < POSE_TOL_M and worst_r < POSE_TOL_RAD, (worst_t, worst_r)
     gpu.close()
+
+
+# ---- scan-to-map refinement (laserMapping.cpp) ---------------------------------------------------------------------
+MAP_GOLDENS = sorted(glob.glob(os.path.join(GOLDEN, "refmap_*.npz")))
+
+
+def _map_frames(g):
+    for k in range(int(g["frames"])):
+        yield k, g[f"odom_q{k}"], g[f"odom_t{k}"], g[f"corner_last{k}"], g[f"surf_last{k}"], g[f"full{k}"]
+
+
+def _cubes_from_golden(g, k, name):
+    ids, cnt, pts = g[f"{name}_ids{k}"], g[f"{name}_cnt{k}"], g[f"{name}_pts{k}"]
+    off = np.concatenate([[0], np.cumsum(cnt)])
+    return {int(c): pts[off[i]:off[i + 1]] for i, c in enumerate(ids)}
+
+
+@pytest.mark.parametrize("path", MAP_GOLDENS)
+def test_mapping_oracle_literal_order_is_bit_exact_with_reference_code(O, path):
+    """Whole cube map, refined pose and map<-odom transform after every frame, against laserMapping.cpp itself."""
+    g = np.load(path)
+    orc = O.Oracle(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), canonical_order=False)
+    orc.map_config(float(g["line_res"]), float(g["plane_res"]))
+    for k, q, t, c, s, f in _map_frames(g):
+        p = orc.mapping_step(q, t, c, s, f)
+        for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+            assert np.abs(p[key] - g[f"{key}{k}"]).max() < 1e-12, (path, k, key)
+        for cls, name in ((0, "corner_map"), (1, "surf_map")):
+            want, got = _cubes_from_golden(g, k, name), orc.map_cubes(cls)
+            assert set(want) == set(got), (path, k, name)
+            for cube in want:
+                assert bits_equal(got[cube], want[cube]), (path, k, name, cube)
+        assert bits_equal(orc.map_cloud(O.MAP_REGISTERED)[::7], g[f"registered_s7_{k}"])
+        info = orc.map_info()
+        assert (info["cenW"], info["cenH"], info["cenD"]) == tuple(int(v) for v in g[f"cen{k}"])
+
+
+@pytest.mark.parametrize("path", MAP_GOLDENS)
+def test_mapping_oracle_canonical_order_vs_reference_code(O, path):
+    """Canonical voxel summation order (what the HIP path does): same cube occupancy, poses within tolerance."""
+    g = np.load(path)
+    orc = O.Oracle(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]))
+    orc.map_config(float(g["line_res"]), float(g["plane_res"]))
+    for k, q, t, c, s, f in _map_frames(g):
+        p = orc.mapping_step(q, t, c, s, f)
+        assert np.abs(p["t_w"] - g[f"t_w{k}"]).max() < POSE_TOL_M and quat_angle(p["q_w"], g[f"q_w{k}"]) < POSE_TOL_RAD
+        for cls, name in ((0, "corner_map"), (1, "surf_map")):
+            want, got = _cubes_from_golden(g, k, name), orc.map_cubes(cls)
+            assert set(want) == set(got)
+            n_w, n_g = sum(len(v) for v in want.values()), sum(len(v) for v in got.values())
+            assert abs(n_w - n_g) <= max(2, n_w // 2000), (path, k, name, n_w, n_g)      # a centroid within 1 ulp of a voxel face may re-bin
+
+
+def test_mapping_cube_window_shift_matches_reference_code(O):
+    """Drive the pose across several 50 m cubes so that the 21 x 21 x 11 window shifts (laserMapping.cpp:323-507)."""
+    import ref_py
+    if not ref_py.available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(3)
+    frames = []
+    for k in range(9):
+        tx, ty, tz = [0, 120, 390, 420, 200, -40, -380, -395, -100][k], [0, -60, -380, -100, 30, 390, 395, 0, 0][k], [0, 0, 30, 160, 170, -120, -130, 0, 0][k]
+        pts = rng.uniform(-60, 60, (1500, 4)).astype(np.float32); pts[:, 3] = rng.integers(0, 16, 1500)
+        surf = rng.uniform(-60, 60, (4000, 4)).astype(np.float32); surf[:, 2] *= 0.05; surf[:, 3] = rng.integers(0, 16, 4000)
+        frames.append(dict(q_w=np.array([0, 0, np.sin(0.1 * k), np.cos(0.1 * k)]), t_w=np.array([tx, ty, tz], float), corner_last=pts, surf_last=surf, cloud=surf[:100]))
+    ref = ref_py.laser_mapping(frames, 0.4, 0.8)
+    orc = O.Oracle(16, 0.3, canonical_order=False)
+    orc.map_config(0.4, 0.8)
+    shifted = False
+    for k, fr in enumerate(frames):
+        p = orc.mapping_step(fr["q_w"], fr["t_w"], fr["corner_last"], fr["surf_last"], fr["cloud"])
+        info = orc.map_info()
+        assert (info["cenW"], info["cenH"], info["cenD"]) == ref[k]["cen"], (k, info, ref[k]["cen"])
+        shifted = shifted or ref[k]["cen"] != (10, 10, 5)
+        for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+            assert np.abs(p[key] - ref[k][key]).max() < 1e-12
+        for cls, name in ((0, "corner_map"), (1, "surf_map")):
+            got = orc.map_cubes(cls)
+            assert set(got) == set(ref[k][name])
+            for cube in got:
+                assert bits_equal(got[cube], ref[k][name][cube]), (k, name, cube)
+    assert shifted

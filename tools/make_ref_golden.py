@@ -38,5 +38,37 @@ def main():
         print(path, os.path.getsize(path) // 1024, "KiB")
 
 
+MAP_CASES = [("refmap_hdl64_c256_seed13", "HDL-64", 6, 13, {"columns": 256}, 0.4, 0.8), ("refmap_vlp16_c600_seed14", "VLP-16", 6, 14, {"columns": 600}, 0.2, 0.4)]
+
+
+def main_mapping():
+    """registration -> odometry -> mapping, all three by the reference's own translation units; the mapping inputs
+    (what the node receives per frame) and outputs (pose, map<-odom transform, the whole cube map) are stored."""
+    for tag, name, frames, seed, kw, line_res, plane_res in MAP_CASES:
+        scans, R, t, model = syn.make_sequence(name, frames, seed=seed, **kw)
+        xs = [s.numpy() for s in scans]
+        reg = ref_py.scan_registration(xs, model.n_scans, model.min_range)
+        odo = ref_py.laser_odometry(reg)
+        fr = [dict(q_w=o["q_w"], t_w=o["t_w"], corner_last=o["corner_last"], surf_last=o["surf_last"], cloud=r["cloud"]) for o, r in zip(odo, reg)]
+        mp = ref_py.laser_mapping(fr, line_res, plane_res)
+        out = {"R": R.numpy(), "t": t.numpy(), "n_scans": model.n_scans, "min_range": model.min_range, "frames": frames, "line_res": line_res, "plane_res": plane_res}
+        for k in range(frames):
+            out[f"odom_q{k}"], out[f"odom_t{k}"] = fr[k]["q_w"], fr[k]["t_w"]
+            out[f"corner_last{k}"], out[f"surf_last{k}"], out[f"full{k}"] = fr[k]["corner_last"], fr[k]["surf_last"], fr[k]["cloud"]
+            for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+                out[f"{key}{k}"] = mp[k][key]
+            out[f"cen{k}"] = np.array(mp[k]["cen"])
+            out[f"registered_s7_{k}"] = mp[k]["registered"][::7].copy()
+            for nm in ("corner_map", "surf_map"):
+                ids = sorted(mp[k][nm])
+                out[f"{nm}_ids{k}"] = np.array(ids, np.int32)
+                out[f"{nm}_cnt{k}"] = np.array([len(mp[k][nm][c]) for c in ids], np.int32)
+                out[f"{nm}_pts{k}"] = np.concatenate([mp[k][nm][c] for c in ids]) if ids else np.zeros((0, 4), np.float32)
+        path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     main()
+    main_mapping()
