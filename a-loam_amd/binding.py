@@ -19,6 +19,9 @@ HEADER_PATH = os.path.join(_ROOT, "include", "aloam_mi355x.h")
 
 CLOUD_FULL, CLOUD_SHARP, CLOUD_LESS_SHARP, CLOUD_FLAT, CLOUD_LESS_FLAT, CLOUD_CORNER_LAST, CLOUD_SURF_LAST = range(7)
 E_ARG, E_SCAN_LINES, E_EMPTY, E_CAPACITY, E_HIP, E_STATE = -1, -2, -3, -4, -5, -6
+MAP_REGISTERED, MAP_CORNER_STACK, MAP_SURF_STACK = 2, 3, 4
+MAP_INFO_KEYS = ("cenW", "cenH", "cenD", "frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack",
+                 "corner_num0", "corner_num1", "surf_num0", "surf_num1", "lm_iterations0", "lm_iterations1", "termination0", "termination1")
 
 
 class AloamConfig(C.Structure):
@@ -91,6 +94,14 @@ def lib():
         L.aloam_get_curvature.argtypes = [vp, C.c_int, vp, C.c_int]
         L.aloam_get_labels.argtypes = [vp, C.c_int, vp, C.c_int]
         L.aloam_get_correspondences.argtypes = [vp, C.c_int, vp, C.c_int, ip, vp, vp, C.c_int, ip, vp]
+        L.aloam_mapping_enable.argtypes = [vp, C.c_float, C.c_float, C.c_int]
+        L.aloam_mapping_step.argtypes = [vp]
+        L.aloam_set_full_cloud.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.aloam_get_map_pose.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+        L.aloam_get_map_info.argtypes = [vp, C.c_int, vp]
+        L.aloam_map_cube_counts.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.aloam_get_map_cube.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int]
+        L.aloam_get_map_cloud.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int]
         L.aloam_profile_enable.argtypes = [vp, C.c_int]
         L.aloam_profile_kernel_count.argtypes = []
         L.aloam_profile_kernel_name.argtypes = [C.c_int]; L.aloam_profile_kernel_name.restype = C.c_char_p
@@ -232,6 +243,53 @@ class Aloam:
         ne, npl = C.c_int(0), C.c_int(0)
         self._check(lib().aloam_get_correspondences(self.h, seq, _p(e), cap_e, C.byref(ne), _p(eq), _p(p), cap_p, C.byref(npl), _p(pq)))
         return e[:ne.value].copy(), p[:npl.value].copy(), eq[:ne.value].copy(), pq[:npl.value].copy()
+
+    # ---- stage 3 -------------------------------------------------------------------------------------------
+    def mapping_enable(self, line_res=0.4, plane_res=0.8, pool_points=262144):
+        self._check(lib().aloam_mapping_enable(self.h, float(line_res), float(plane_res), int(pool_points)))
+
+    def mapping_step(self):
+        self._check(lib().aloam_mapping_step(self.h))
+
+    def set_full_cloud(self, cloud, seq=0):
+        a = _f32(cloud)
+        self._check(lib().aloam_set_full_cloud(self.h, seq, _p(a), len(a)))
+
+    def mapping_step_inputs(self, q_wodom, t_wodom, corner_last, surf_last, full_res, seq=0):
+        """Teacher-forced frame: inject what the mapping node receives (reference src/laserMapping.cpp:175-228), then step."""
+        self.set_last(corner_last, surf_last, seq)
+        self.set_full_cloud(full_res, seq)
+        p = self.pose(seq)
+        self.set_state(p["q_lc"], p["t_lc"], q_wodom, t_wodom, seq)
+        self.mapping_step()
+        return self.map_pose(seq)
+
+    def map_pose(self, seq=0):
+        qw, tw, qm, tm = np.zeros(4), np.zeros(3), np.zeros(4), np.zeros(3)
+        self._check(lib().aloam_get_map_pose(self.h, seq, _p(qw), _p(tw), _p(qm), _p(tm)))
+        return {"q_w": qw, "t_w": tw, "q_wmap_wodom": qm, "t_wmap_wodom": tm}
+
+    def map_info(self, seq=0):
+        v = np.zeros(16, np.int32)
+        self._check(lib().aloam_get_map_info(self.h, seq, _p(v)))
+        return dict(zip(MAP_INFO_KEYS, (int(x) for x in v)))
+
+    def map_cubes(self, cls, seq=0):
+        cnt = np.zeros(21 * 21 * 11, np.int32)
+        self._check(lib().aloam_map_cube_counts(self.h, seq, cls, _p(cnt)))
+        out = {}
+        for i in np.nonzero(cnt)[0]:
+            pts = np.zeros((int(cnt[i]), 4), np.float32)
+            self._check(lib().aloam_get_map_cube(self.h, seq, cls, int(i), _p(pts), len(pts)))
+            out[int(i)] = pts
+        return out
+
+    def map_cloud(self, which, seq=0):
+        n = self._check(lib().aloam_get_map_cloud(self.h, seq, which, None, 0))
+        out = np.zeros((n, 4), np.float32)
+        if n:
+            self._check(lib().aloam_get_map_cloud(self.h, seq, which, _p(out), n))
+        return out
 
     # ---- profiling -----------------------------------------------------------------------------------------
     def profile_enable(self, on=True):

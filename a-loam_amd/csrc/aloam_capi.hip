@@ -3,13 +3,16 @@
 // without a HIP device every entry point fails with ALOAM_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/aloam_mi355x.h"
 #include "aloam_device.hpp"
+#include "mapping_kernels.hpp"
 #include "odometry_kernels.hpp"
 #include "registration_kernels.hpp"
 
@@ -17,7 +20,8 @@ using namespace aloam;
 
 namespace {
 enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_COMPACT, K_BUILD_GRIDS, K_ASSOC_CORNER,
-                K_ASSOC_PLANE, K_SOLVE, K_ADVANCE, K_COUNT };
+                K_ASSOC_PLANE, K_SOLVE, K_ADVANCE, K_MAP_BEGIN, K_MAP_VOXEL_STACK, K_MAP_GRID, K_MAP_ASSOC, K_MAP_SOLVE, K_MAP_INSERT,
+                K_MAP_VOXEL_CUBES, K_MAP_REGISTER, K_COUNT };
 const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_classify", "k_ring_offsets", "k_scatter", "k_ring_features",
                                      "k_compact_features", "k_build_grids", "k_associate[corner]", "k_associate[plane]",
                                      "k_solve", "k_advance"};
@@ -50,6 +54,18 @@ struct aloam_ctx {
   int grid_H[2] = {4096, 16384};
   bool grids_valid = false;          // the grids describe the current "last" clouds
   EdgeRec* d_edges = nullptr; PlaneRec* d_planes = nullptr;
+  // scan-to-map refinement (allocated by aloam_mapping_enable)
+  bool map_on = false;
+  float map_line_res = 0.4f, map_plane_res = 0.8f;
+  int map_pool = 0, map_H[2] = {0, 0}, map_levels = 0, map_tile_cap = 0, map_tile_bound[2] = {0, 0}, map_nsegs_max = 0;
+  long long map_key_cap = 0;
+  MapSeq* d_mapseq = nullptr; CubeDesc* d_cubes = nullptr; float4* d_pool[2] = {nullptr, nullptr}; int* d_maptab = nullptr;
+  float4* d_stack[2] = {nullptr, nullptr}; float4* d_stack_world[2] = {nullptr, nullptr}; int* d_stack_cube[2] = {nullptr, nullptr};
+  int *d_addcnt = nullptr, *d_cursor = nullptr;
+  float4* d_mgrid_sorted[2] = {nullptr, nullptr}; int* d_mgrid_start[2] = {nullptr, nullptr}; int* d_mgrid_cnt[2] = {nullptr, nullptr};
+  MapEdgeRec* d_medges = nullptr; MapNormRec* d_mnorms = nullptr; float4* d_registered = nullptr;
+  VoxSeg* d_segs = nullptr; int *d_tile_seg = nullptr, *d_tile_heads = nullptr, *d_tile_pref = nullptr, *d_vox_counters = nullptr, *d_bbox = nullptr;
+  unsigned long long* d_keys[2] = {nullptr, nullptr}; float4* d_voxtmp = nullptr;
   bool system_inited = false;        // reference src/laserOdometry.cpp:69
   bool have_features = false;
   // profiling
@@ -267,7 +283,11 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
                   c->d_grid_start2[0], c->d_grid_start2[1], c->d_grid_first_ge[0], c->d_grid_first_ge[1], c->d_grid_last_le[0], c->d_grid_last_le[1],
-                  c->d_grid_flags[0], c->d_grid_flags[1]};
+                  c->d_grid_flags[0], c->d_grid_flags[1],
+                  c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
+                  c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
+                  c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
+                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -285,6 +305,14 @@ int aloam_synchronize(aloam_ctx* c) {
   for (int b = 0; b < c->B; ++b) {
     if (m[b].err & kErrEmpty) { c->err = "sequence " + std::to_string(b) + ": no point survives the NaN / minimum-range filter"; return ALOAM_E_EMPTY; }
     if (m[b].err & (kErrRingCap | kErrPointCap)) { c->err = "sequence " + std::to_string(b) + ": a ring exceeds max_ring_points or the scan exceeds max_points"; return ALOAM_E_CAPACITY; }
+  }
+  if (c->map_on) {
+    std::vector<MapSeq> ms(c->B);
+    int vc[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(ms.data(), c->d_mapseq, sizeof(MapSeq) * c->B, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(vc, c->d_vox_counters, sizeof(vc), hipMemcpyDeviceToHost));
+    if (vc[1]) { c->err = "mapping: voxel-filter scratch too small for the map (raise pool_points) or a cube holds more than 2^" + std::to_string(11 + c->map_levels) + " points"; return ALOAM_E_CAPACITY; }
+    for (int b = 0; b < c->B; ++b) if (ms[b].err & kMapErrPool) { c->err = "sequence " + std::to_string(b) + ": map pool exhausted (raise pool_points)"; return ALOAM_E_CAPACITY; }
   }
   return ALOAM_OK;
 }
@@ -571,6 +599,199 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
     *algorithmic_bytes = bytes;
   }
   return ALOAM_OK;
+}
+
+// ---- stage 3: scan-to-map refinement --------------------------------------------------------------------------------
+static MapArgs map_args(aloam_ctx* c) {
+  MapArgs a{};
+  a.B = c->B; a.cap = c->cap; a.R = c->R;
+  a.meta = c->d_meta; a.odom = c->d_state; a.seq = c->d_mapseq;
+  a.line_res = c->map_line_res; a.plane_res = c->map_plane_res;
+  // after aloam_odometry_step's swap the sweep just processed is the "last" one: exactly what the odometry node publishes
+  // as /laser_cloud_corner_last, /laser_cloud_surf_last and /velodyne_cloud_3 (reference src/laserOdometry.cpp:570-591)
+  a.corner_last = c->d_less_sharp[1 - c->cur]; a.surf_last = c->d_less_flat[1 - c->cur]; a.full = c->d_cloud;
+  a.registered = c->d_registered;
+  a.cubes = c->d_cubes; a.pool_cap = c->map_pool; a.tab = c->d_maptab;
+  for (int k = 0; k < 2; ++k) {
+    a.pool[k] = c->d_pool[k]; a.stack[k] = c->d_stack[k]; a.stack_world[k] = c->d_stack_world[k]; a.stack_cube[k] = c->d_stack_cube[k];
+    a.grid_sorted[k] = c->d_mgrid_sorted[k]; a.grid_start[k] = c->d_mgrid_start[k]; a.grid_cnt[k] = c->d_mgrid_cnt[k]; a.grid_H[k] = c->map_H[k];
+  }
+  a.addcnt = c->d_addcnt; a.cursor = c->d_cursor;
+  a.edges = c->d_medges; a.norms = c->d_mnorms;
+  a.lm_max_iterations = c->cfg.lm_max_iterations;
+  return a;
+}
+static VoxArgs vox_args(aloam_ctx* c, int n_segs) {
+  VoxArgs v{};
+  v.segs = c->d_segs; v.n_segs = n_segs; v.tile_seg = c->d_tile_seg; v.tile_heads = c->d_tile_heads; v.tile_pref = c->d_tile_pref;
+  v.counters = c->d_vox_counters; v.keys[0] = c->d_keys[0]; v.keys[1] = c->d_keys[1]; v.tmp = c->d_voxtmp; v.bbox = c->d_bbox;
+  v.tile_cap = c->map_tile_cap; v.key_cap = c->map_key_cap; v.levels = c->map_levels;
+  return v;
+}
+
+int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool_points) {
+  if (!c) return ALOAM_E_ARG;
+  if (c->map_on) { c->err = "mapping already enabled"; return ALOAM_E_STATE; }
+  if (!(line_res > 0.f) || !(plane_res > 0.f) || pool_points < 4096) { c->err = "bad mapping parameters (pool_points >= 4096)"; return ALOAM_E_ARG; }
+  const size_t B = c->B, cap = c->cap, R = c->R;
+  c->map_line_res = line_res; c->map_plane_res = plane_res;
+  c->map_pool = (pool_points + 1023) / 1024 * 1024;
+  const size_t pool = c->map_pool;
+  for (int k = 0; k < 2; ++k) { int H = 4096; while (H < (int)pool / 2 && H < (1 << 20)) H <<= 1; c->map_H[k] = H; }
+  const size_t max_seg = std::max(cap, pool);
+  c->map_levels = 0;
+  while (((size_t)kVoxTile << c->map_levels) < max_seg) ++c->map_levels;
+  const size_t T = kVoxTile;
+  c->map_tile_bound[0] = (int)(B * ((cap + T - 1) / T + (R * 120 + T - 1) / T));
+  c->map_tile_bound[1] = (int)(B * (2 * pool / T + 2 * kMapValidMax));
+  c->map_tile_cap = std::max(c->map_tile_bound[0], c->map_tile_bound[1]);
+  c->map_key_cap = (long long)(B * std::max(cap + R * 120, 2 * pool));
+  c->map_nsegs_max = (int)(B * 2 * kMapValidMax);
+  int rc = 0;
+  if ((rc = dmalloc(c, &c->d_mapseq, B))) return rc;
+  if ((rc = dmalloc(c, &c->d_cubes, B * 2 * kMapCubes))) return rc;
+  if ((rc = dmalloc(c, &c->d_maptab, B * kTabInts))) return rc;
+  if ((rc = dmalloc(c, &c->d_addcnt, B * 2 * kMapCubes))) return rc;
+  if ((rc = dmalloc(c, &c->d_cursor, B * 2 * kMapCubes))) return rc;
+  for (int k = 0; k < 2; ++k) {
+    const size_t per = k == 0 ? R * 120 : cap;
+    if ((rc = dmalloc(c, &c->d_pool[k], B * pool))) return rc;
+    if ((rc = dmalloc(c, &c->d_stack[k], B * per))) return rc;
+    if ((rc = dmalloc(c, &c->d_stack_world[k], B * per))) return rc;
+    if ((rc = dmalloc(c, &c->d_stack_cube[k], B * per))) return rc;
+    if ((rc = dmalloc(c, &c->d_mgrid_sorted[k], B * pool))) return rc;
+    if ((rc = dmalloc(c, &c->d_mgrid_start[k], B * ((size_t)c->map_H[k] + 1)))) return rc;
+    if ((rc = dmalloc(c, &c->d_mgrid_cnt[k], B * (size_t)c->map_H[k]))) return rc;
+    if ((rc = dmalloc(c, &c->d_keys[k], (size_t)c->map_key_cap))) return rc;
+  }
+  if ((rc = dmalloc(c, &c->d_medges, B * R * 120))) return rc;
+  if ((rc = dmalloc(c, &c->d_mnorms, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_registered, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_segs, (size_t)c->map_nsegs_max))) return rc;
+  if ((rc = dmalloc(c, &c->d_tile_seg, (size_t)c->map_tile_cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_tile_heads, (size_t)c->map_tile_cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_tile_pref, (size_t)c->map_tile_cap + 1))) return rc;
+  if ((rc = dmalloc(c, &c->d_vox_counters, 4))) return rc;
+  if ((rc = dmalloc(c, &c->d_bbox, (size_t)c->map_nsegs_max * 6))) return rc;
+  if ((rc = dmalloc(c, &c->d_voxtmp, (size_t)c->map_key_cap))) return rc;
+  std::vector<MapSeq> init(B);
+  std::memset(init.data(), 0, sizeof(MapSeq) * B);
+  for (size_t b = 0; b < B; ++b) {                       // reference src/laserMapping.cpp:72-74,109,115
+    init[b].par[3] = 1.0; init[b].q_wmap_wodom[3] = 1.0;
+    init[b].cen[0] = 10; init[b].cen[1] = 10; init[b].cen[2] = 5;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_mapseq, init.data(), sizeof(MapSeq) * B, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->map_on = true;
+  return ALOAM_OK;
+}
+
+int aloam_mapping_step(aloam_ctx* c) {
+  if (!c) return ALOAM_E_ARG;
+  if (!c->map_on) { c->err = "aloam_mapping_step before aloam_mapping_enable"; return ALOAM_E_STATE; }
+  const MapArgs a = map_args(c);
+  { ProfScope p(c, K_MAP_BEGIN); launch_map_begin(a, c->stream); }
+  { ProfScope p(c, K_MAP_VOXEL_STACK);                                      // downSizeFilterCorner / Surf on the incoming clouds (:542-550)
+    const VoxArgs v = vox_args(c, c->B * 2);
+    launch_map_stack_segments(a, v, c->stream);
+    launch_voxel_filter(v, c->map_tile_bound[0], c->stream); }
+  { ProfScope p(c, K_MAP_GRID); launch_map_grid(a, c->stream); }            // kdtree*FromMap->setInputCloud (:558-559)
+  for (int iter = 0; iter < 2; ++iter) {                                    // :562
+    { ProfScope p(c, K_MAP_ASSOC); launch_map_associate(a, iter, c->stream); }
+    { ProfScope p(c, K_MAP_SOLVE); launch_map_solve(a, iter, iter == 1, c->stream); }
+  }
+  { ProfScope p(c, K_MAP_INSERT); launch_map_insert(a, c->stream); }        // :737-783
+  if (!getenv("ALOAM_DEBUG_SKIP_REFILTER"))
+  { ProfScope p(c, K_MAP_VOXEL_CUBES);                                      // per-cube re-filter (:788-801)
+    const VoxArgs v = vox_args(c, c->B * 2 * kMapValidMax);
+    launch_map_cube_segments(a, v, c->stream);
+    launch_voxel_filter(v, c->map_tile_bound[1], c->stream); }
+  { ProfScope p(c, K_MAP_REGISTER); launch_map_register(a, c->stream); }    // :836-846
+  HIP_TRY(c, hipGetLastError());
+  return ALOAM_OK;
+}
+
+int aloam_set_full_cloud(aloam_ctx* c, int seq, const float* cloud, int n) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if (n < 0 || n > c->cap) { c->err = "cloud too large"; return ALOAM_E_CAPACITY; }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (n) HIP_TRY(c, hipMemcpy(c->d_cloud + (size_t)seq * c->cap, cloud, sizeof(float4) * n, hipMemcpyHostToDevice));
+  SeqMeta m;
+  HIP_TRY(c, hipMemcpy(&m, c->d_meta + seq, sizeof(SeqMeta), hipMemcpyDeviceToHost));
+  m.n_cloud = n;
+  HIP_TRY(c, hipMemcpy(c->d_meta + seq, &m, sizeof(SeqMeta), hipMemcpyHostToDevice));
+  return ALOAM_OK;
+}
+
+static int fetch_mapseq(aloam_ctx* c, int seq, MapSeq* ms) {
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if (!c->map_on) { c->err = "mapping not enabled"; return ALOAM_E_STATE; }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(ms, c->d_mapseq + seq, sizeof(MapSeq), hipMemcpyDeviceToHost));
+  return ALOAM_OK;
+}
+
+int aloam_get_map_pose(aloam_ctx* c, int seq, double q_w_curr[4], double t_w_curr[3], double q_wmap_wodom[4], double t_wmap_wodom[3]) {
+  MapSeq ms;
+  const int rc = fetch_mapseq(c, seq, &ms);
+  if (rc) return rc;
+  for (int k = 0; k < 4; ++k) { q_w_curr[k] = ms.par[k]; q_wmap_wodom[k] = ms.q_wmap_wodom[k]; }
+  for (int k = 0; k < 3; ++k) { t_w_curr[k] = ms.par[4 + k]; t_wmap_wodom[k] = ms.t_wmap_wodom[k]; }
+  return ALOAM_OK;
+}
+
+int aloam_get_map_info(aloam_ctx* c, int seq, int out[16]) {
+  MapSeq ms;
+  const int rc = fetch_mapseq(c, seq, &ms);
+  if (rc) return rc;
+  const int v[16] = {ms.cen[0], ms.cen[1], ms.cen[2], ms.frame_count, ms.from_total[0], ms.from_total[1], ms.n_stack[0], ms.n_stack[1],
+                     ms.factor_num[0][0], ms.factor_num[1][0], ms.factor_num[0][1], ms.factor_num[1][1], ms.lm_iterations[0], ms.lm_iterations[1],
+                     ms.lm_termination[0], ms.lm_termination[1]};
+  std::memcpy(out, v, sizeof(v));
+  return ALOAM_OK;
+}
+
+int aloam_map_cube_counts(aloam_ctx* c, int seq, int cls, int* out) {
+  MapSeq ms;
+  const int rc = fetch_mapseq(c, seq, &ms);
+  if (rc) return rc;
+  if (cls < 0 || cls > 1) { c->err = "class must be 0 (corner) or 1 (surf)"; return ALOAM_E_ARG; }
+  std::vector<CubeDesc> d(kMapCubes);
+  HIP_TRY(c, hipMemcpy(d.data(), c->d_cubes + ((size_t)seq * 2 + cls) * kMapCubes, sizeof(CubeDesc) * kMapCubes, hipMemcpyDeviceToHost));
+  for (int i = 0; i < kMapCubes; ++i) out[i] = d[i].cnt;
+  return kMapCubes;
+}
+
+int aloam_get_map_cube(aloam_ctx* c, int seq, int cls, int cube, float* out, int cap_points) {
+  MapSeq ms;
+  const int rc = fetch_mapseq(c, seq, &ms);
+  if (rc) return rc;
+  if (cls < 0 || cls > 1 || cube < 0 || cube >= kMapCubes) { c->err = "bad class / cube index"; return ALOAM_E_ARG; }
+  CubeDesc d;
+  HIP_TRY(c, hipMemcpy(&d, c->d_cubes + ((size_t)seq * 2 + cls) * kMapCubes + cube, sizeof(CubeDesc), hipMemcpyDeviceToHost));
+  const int k = d.cnt < cap_points ? d.cnt : cap_points;
+  if (k > 0) HIP_TRY(c, hipMemcpy(out, c->d_pool[cls] + (size_t)seq * c->map_pool + d.off, sizeof(float4) * k, hipMemcpyDeviceToHost));
+  return d.cnt;
+}
+
+int aloam_get_map_cloud(aloam_ctx* c, int seq, int which, float* out, int cap_points) {
+  MapSeq ms;
+  const int rc = fetch_mapseq(c, seq, &ms);
+  if (rc) return rc;
+  const float4* p = nullptr;
+  int n = 0;
+  if (which == ALOAM_MAP_REGISTERED) {
+    SeqMeta m;
+    HIP_TRY(c, hipMemcpy(&m, c->d_meta + seq, sizeof(SeqMeta), hipMemcpyDeviceToHost));
+    p = c->d_registered + (size_t)seq * c->cap; n = m.n_cloud;
+  } else if (which == ALOAM_MAP_CORNER_STACK) { p = c->d_stack[0] + (size_t)seq * c->R * 120; n = ms.n_stack[0]; }
+  else if (which == ALOAM_MAP_SURF_STACK) { p = c->d_stack[1] + (size_t)seq * c->cap; n = ms.n_stack[1]; }
+  else { c->err = "unknown map cloud id"; return ALOAM_E_ARG; }
+  const int k = n < cap_points ? n : cap_points;
+  if (k > 0) HIP_TRY(c, hipMemcpy(out, p, sizeof(float4) * k, hipMemcpyDeviceToHost));
+  return n;
 }
 
 }  // extern "C"

@@ -211,4 +211,22 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// LDS bitonic sort of npad (power of two) 64-bit keys, ascending, 256 threads.
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int npad, int tid) {
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += 256) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i + j;
+        const unsigned long long x = keys[i], y = keys[l];
+        const bool up = (i & k) == 0;
+        if ((x > y) == up) { keys[i] = y; keys[l] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
 }  // namespace aloam

@@ -1,0 +1,985 @@
+// a-loam_amd/csrc/mapping_kernels.hip — gfx950 kernels for A-LOAM scan-to-map refinement.
+//
+// Replaces, for a BATCH of independent sequences, the body of process() in the reference's src/laserMapping.cpp:231-893
+// (one frame per call, no frame dropping) and the third-party calls inside it.  Kernel <-> reference map:
+//   k_map_begin        :142-146 transformAssociateToMap, :311-321 centre cube, :323-507 window shifts (the 21 x 21 x 11
+//                      pointer grid becomes a table of cube descriptors), :509-539 valid cubes + submap prefixes
+//   k_vox_*            pcl::VoxelGrid::filter (:542-550 incoming clouds, :788-801 per-cube re-filter): bounding box ->
+//                      (voxel, index) 64-bit keys -> tile sort in LDS + rank-merge levels -> segment heads -> centroids in
+//                      input order; any number of independent segments per launch
+//   k_mapgrid_*        pcl::KdTreeFLANN::setInputCloud (:558-559): 1 m cell hash over the submap (global counting sort)
+//   k_map_associate    :576-706  pointAssociateToMap, nearestKSearch(k = 5) as an exact fixed-radius search (the reference
+//                      only uses the result when the 5th neighbour is closer than 1 m), line fit (3x3 symmetric
+//                      eigen-decomposition) / plane fit (5x3 least squares), factor records
+//   k_map_solve        :565-572,712-720 ceres::Solve over LidarEdgeFactor + LidarPlaneNormFactor blocks (shared LM loop,
+//                      lm_device.hpp), then :148-152 transformUpdate
+//   k_map_cubeid / k_map_reserve / k_map_scatter   :737-783 map insertion (stable append per cube)
+//   k_map_register     :836-846 /velodyne_cloud_registered
+// Everything is integer / f32 / f64 scalar work on 16-byte point records: HBM- and latency-bound, no MFMA.
+#include "mapping_kernels.hpp"
+
+#include "lm_device.hpp"
+
+namespace aloam {
+
+namespace {
+
+__device__ __forceinline__ int f2o(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7fffffff; }   // order-preserving
+__device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__device__ __forceinline__ unsigned hash_cell(int a, int b, int c) {
+  return ((unsigned)a * 73856093u) ^ ((unsigned)b * 19349663u) ^ ((unsigned)c * 83492791u);
+}
+
+// Hamilton product a * b (x,y,z,w storage), as Eigen evaluates it.
+__device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4]) {
+  o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+  o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+  o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+}
+
+// pointAssociateToMap (reference src/laserMapping.cpp:157-166): f64 rotation + translation, stored back to f32.
+__device__ __forceinline__ float4 associate_to_map(const float4& p, const double par[7]) {
+  double o[3];
+  quat_rotate(par, (double)p.x, (double)p.y, (double)p.z, o);
+  return make_float4((float)(o[0] + par[4]), (float)(o[1] + par[5]), (float)(o[2] + par[6]), p.w);
+}
+
+// int((v + 25.0) / 50.0) + cen, minus one when v + 25 < 0  (:312-321, :741-750)
+__device__ __forceinline__ int cube_coord(double v, int cen) {
+  int c = (int)((v + 25.0) / 50.0) + cen;
+  if (v + 25.0 < 0) c--;
+  return c;
+}
+
+__device__ __forceinline__ CubeDesc* cube_table(const MapArgs& a, int b, int cls) { return a.cubes + ((long long)b * 2 + cls) * kMapCubes; }
+
+// submap lookup: g-th point of the concatenated valid cubes of class cls (laserCloudCornerFromMap / SurfFromMap order)
+__device__ __forceinline__ float4 submap_point(const MapArgs& a, int b, int cls, const int* tab, int n_valid, int g) {
+  const int* pref = tab + 80 + cls * 80;
+  int lo = 0, hi = n_valid - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pref[mid] <= g) lo = mid; else hi = mid - 1; }
+  const CubeDesc d = cube_table(a, b, cls)[tab[lo]];
+  return a.pool[cls][(long long)b * a.pool_cap + d.off + (g - pref[lo])];
+}
+
+}  // namespace
+
+// =======================================================================================================
+// frame set-up
+// =======================================================================================================
+__global__ __launch_bounds__(256) void k_map_begin(MapArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  MapSeq& ms = a.seq[b];
+  __shared__ int s_c[3], s_cen[3];
+  if (tid == 0) {
+    const OdomState& od = a.odom[b];
+    double qo[4], to[3], qm[4], q[4], rt[3];
+    for (int k = 0; k < 4; ++k) { qo[k] = od.q_w[k]; qm[k] = ms.q_wmap_wodom[k]; ms.q_wodom[k] = qo[k]; }
+    for (int k = 0; k < 3; ++k) { to[k] = od.t_w[k]; ms.t_wodom[k] = to[k]; }
+    quat_mul(qm, qo, q);                                                   // transformAssociateToMap (:142-146)
+    quat_rotate(qm, to[0], to[1], to[2], rt);
+    for (int k = 0; k < 4; ++k) ms.par[k] = q[k];
+    for (int k = 0; k < 3; ++k) ms.par[4 + k] = rt[k] + ms.t_wmap_wodom[k];
+    for (int k = 0; k < 3; ++k) { s_cen[k] = ms.cen[k]; s_c[k] = cube_coord(ms.par[4 + k], ms.cen[k]); }
+  }
+  __syncthreads();
+  // window shifts (:323-507): the descriptors move, the slab that falls off re-enters emptied at the other end
+  const int dim[3] = {kMapW, kMapH, kMapD};
+  for (int axis = 0; axis < 3; ++axis) {
+    for (int guard = 0; guard < 64; ++guard) {
+      const int c = s_c[axis], n = dim[axis];
+      const int dir = c < 3 ? 1 : (c >= n - 3 ? -1 : 0);
+      if (dir == 0) break;
+      const int nu = dim[(axis + 1) % 3], nv = dim[(axis + 2) % 3];
+      for (int line = tid; line < nu * nv * 2; line += 256) {
+        const int cls = line / (nu * nv), u = (line % (nu * nv)) / nv, v = line % nv;
+        CubeDesc* T = cube_table(a, b, cls);
+        auto at = [&](int x) {
+          int ijk[3];
+          ijk[axis] = x; ijk[(axis + 1) % 3] = u; ijk[(axis + 2) % 3] = v;
+          return ijk[0] + kMapW * ijk[1] + kMapW * kMapH * ijk[2];
+        };
+        if (dir > 0) {
+          CubeDesc keep = T[at(n - 1)];
+          for (int x = n - 1; x >= 1; --x) T[at(x)] = T[at(x - 1)];
+          keep.cnt = 0;
+          T[at(0)] = keep;
+        } else {
+          CubeDesc keep = T[at(0)];
+          for (int x = 0; x < n - 1; ++x) T[at(x)] = T[at(x + 1)];
+          keep.cnt = 0;
+          T[at(n - 1)] = keep;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) { s_c[axis] += dir; s_cen[axis] += dir; }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) {
+    int* tab = a.tab + (long long)b * kTabInts;
+    const CubeDesc* Tc = cube_table(a, b, 0);
+    const CubeDesc* Ts = cube_table(a, b, 1);
+    int nvld = 0, pc = 0, ps = 0;
+    for (int i = s_c[0] - 2; i <= s_c[0] + 2; i++)
+      for (int j = s_c[1] - 2; j <= s_c[1] + 2; j++)
+        for (int k = s_c[2] - 1; k <= s_c[2] + 1; k++)
+          if (i >= 0 && i < kMapW && j >= 0 && j < kMapH && k >= 0 && k < kMapD) {
+            const int ind = i + kMapW * j + kMapW * kMapH * k;
+            tab[nvld] = ind;
+            tab[80 + nvld] = pc;
+            tab[160 + nvld] = ps;
+            pc += Tc[ind].cnt;
+            ps += Ts[ind].cnt;
+            ++nvld;
+          }
+    tab[80 + nvld] = pc;
+    tab[160 + nvld] = ps;
+    ms.n_valid = nvld;
+    ms.from_total[0] = pc;
+    ms.from_total[1] = ps;
+    ms.gate = (pc > 10 && ps > 50) ? 1 : 0;                                 // :554
+    for (int k = 0; k < 3; ++k) { ms.cen[k] = s_cen[k]; ms.center[k] = s_c[k]; }
+    for (int it = 0; it < 2; ++it) { ms.factor_num[it][0] = ms.factor_num[it][1] = 0; ms.lm_iterations[it] = 0; ms.lm_termination[it] = 4; }
+  }
+}
+
+// =======================================================================================================
+// pcl::VoxelGrid for any number of independent segments
+// =======================================================================================================
+__global__ void k_map_stack_segments(MapArgs a, VoxArgs v) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.B * 2) return;
+  const int b = g >> 1, cls = g & 1;
+  VoxSeg s{};
+  s.in = cls == 0 ? a.corner_last + (long long)b * a.R * 120 : a.surf_last + (long long)b * a.cap;
+  s.n = cls == 0 ? a.meta[b].n_corner_last : a.meta[b].n_surf_last;
+  s.out = a.stack[cls] + (long long)b * (cls == 0 ? a.R * 120 : a.cap);
+  s.out_count = &a.seq[b].n_stack[cls];
+  s.final_out = nullptr;
+  s.final_count = nullptr;
+  s.leaf = cls == 0 ? a.line_res : a.plane_res;                             // downSizeFilterCorner / Surf (:904-905)
+  v.segs[g] = s;
+}
+
+__global__ void k_map_cube_segments(MapArgs a, VoxArgs v) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.B * 2 * kMapValidMax) return;
+  const int j = g % kMapValidMax, cls = (g / kMapValidMax) & 1, b = g / (2 * kMapValidMax);
+  VoxSeg s{};
+  s.leaf = cls == 0 ? a.line_res : a.plane_res;
+  if (j < a.seq[b].n_valid) {
+    CubeDesc* d = cube_table(a, b, cls) + a.tab[(long long)b * kTabInts + j];
+    s.in = a.pool[cls] + (long long)b * a.pool_cap + d->off;
+    s.n = d->cnt;
+    s.final_out = a.pool[cls] + (long long)b * a.pool_cap + d->off;
+    s.final_count = &d->cnt;
+  }
+  v.segs[g] = s;
+}
+
+// key offsets, tile work list, bounding-box reset.  One 1024-thread workgroup.
+__global__ __launch_bounds__(1024) void k_vox_setup(VoxArgs v) {
+  const int tid = threadIdx.x;
+  __shared__ long long s_keys[1024];
+  __shared__ int s_tiles[1024];
+  const int per = (v.n_segs + 1023) / 1024;
+  const int s0 = tid * per, s1 = min(v.n_segs, s0 + per);
+  long long kk = 0;
+  int tt = 0;
+  for (int s = s0; s < s1; ++s) { const int n = v.segs[s].n; kk += n; tt += (n + kVoxTile - 1) / kVoxTile; }
+  s_keys[tid] = kk;
+  s_tiles[tid] = tt;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const long long ak = tid >= d ? s_keys[tid - d] : 0;
+    const int at = tid >= d ? s_tiles[tid - d] : 0;
+    __syncthreads();
+    s_keys[tid] += ak;
+    s_tiles[tid] += at;
+    __syncthreads();
+  }
+  const long long total_keys = s_keys[1023];
+  const int total_tiles = s_tiles[1023];
+  const bool bad = total_keys > v.key_cap || total_tiles > v.tile_cap;
+  long long ko = s_keys[tid] - kk;
+  int to = s_tiles[tid] - tt;
+  for (int s = s0; s < s1; ++s) {
+    VoxSeg& sg = v.segs[s];
+    if (bad || sg.n > (kVoxTile << v.levels)) {                              // skipped, reported through counters[1]
+      if (!bad) atomicOr(&v.counters[1], kMapErrSegment);
+      sg.n = 0; sg.final_out = nullptr; sg.final_count = nullptr;
+    }
+    const int n = sg.n, nt = (n + kVoxTile - 1) / kVoxTile;
+    sg.key_off = (int)ko;
+    sg.tile0 = to;
+    sg.ntiles = nt;
+    if (sg.final_out) sg.out = v.tmp + ko;
+    if (!bad) for (int t = 0; t < nt; ++t) v.tile_seg[to + t] = s;
+    for (int q = 0; q < 3; ++q) { v.bbox[s * 6 + q] = 0x7fffffff; v.bbox[s * 6 + 3 + q] = (int)0x80000000; }
+    ko += n;
+    to += nt;
+  }
+  if (tid == 0) { v.counters[0] = bad ? 0 : total_tiles; if (bad) atomicOr(&v.counters[1], kMapErrKeys); }
+}
+
+__global__ __launch_bounds__(256) void k_vox_bbox(VoxArgs v) {
+  const int gt = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  if (gt >= v.counters[0]) return;
+  const int s = v.tile_seg[gt];
+  const VoxSeg sg = v.segs[s];
+  const int t = gt - sg.tile0;
+  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+  for (int e = tid; e < kVoxTile; e += 256) {
+    const int i = t * kVoxTile + e;
+    if (i < sg.n) {
+      const float4 p = sg.in[i];
+      mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+      mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+      mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    for (int d = 32; d > 0; d >>= 1) { mn[q] = fminf(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = fmaxf(mx[q], __shfl_down(mx[q], d, 64)); }
+    if (lane == 0) { atomicMin(&v.bbox[s * 6 + q], f2o(mn[q])); atomicMax(&v.bbox[s * 6 + 3 + q], f2o(mx[q])); }
+  }
+}
+
+// (voxel index, point index) keys of one tile, sorted in LDS.
+__global__ __launch_bounds__(256) void k_vox_keys_sort(VoxArgs v) {
+  const int gt = blockIdx.x, tid = threadIdx.x;
+  if (gt >= v.counters[0]) return;
+  const int s = v.tile_seg[gt];
+  const VoxSeg sg = v.segs[s];
+  const int t = gt - sg.tile0;
+  __shared__ unsigned long long keys[kVoxTile];
+  const float inv = 1.0f / sg.leaf;
+  float gmn[3], gmx[3], fminb[3];
+  int divb[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { gmn[q] = o2f(v.bbox[s * 6 + q]); gmx[q] = o2f(v.bbox[s * 6 + 3 + q]); }
+  const long long dx = (long long)((gmx[0] - gmn[0]) * inv) + 1, dy = (long long)((gmx[1] - gmn[1]) * inv) + 1, dz = (long long)((gmx[2] - gmn[2]) * inv) + 1;
+  const bool overflow = dx * dy * dz > 2147483647ll;                      // PCL then returns the input unfiltered
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int minb = (int)floorf(gmn[q] * inv);
+    divb[q] = (int)floorf(gmx[q] * inv) - minb + 1;
+    fminb[q] = (float)minb;
+  }
+  for (int e = tid; e < kVoxTile; e += 256) {
+    const int i = t * kVoxTile + e;
+    unsigned long long key = ~0ull;
+    if (i < sg.n) {
+      unsigned vi;
+      if (overflow) vi = (unsigned)i;
+      else {
+        const float4 p = sg.in[i];
+        const int i0 = (int)(floorf(p.x * inv) - fminb[0]);
+        const int i1 = (int)(floorf(p.y * inv) - fminb[1]);
+        const int i2 = (int)(floorf(p.z * inv) - fminb[2]);
+        vi = (unsigned)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]);
+      }
+      key = ((unsigned long long)vi << 32) | (unsigned)i;
+    }
+    keys[e] = key;
+  }
+  __syncthreads();
+  bitonic_sort_u64(keys, kVoxTile, tid);
+  unsigned long long* dst = v.keys[0] + sg.key_off;
+  for (int e = tid; e < kVoxTile; e += 256) { const int i = t * kVoxTile + e; if (i < sg.n) dst[i] = keys[e]; }
+}
+
+// One rank-merge level: runs of `run` keys are merged pairwise; every key finds its place by a binary search in the sibling
+// run (keys are unique, so no tie rule is needed).  src = keys[level & 1], dst = the other buffer.
+__global__ __launch_bounds__(256) void k_vox_merge(VoxArgs v, int level) {
+  const int gt = blockIdx.x, tid = threadIdx.x;
+  if (gt >= v.counters[0]) return;
+  const VoxSeg sg = v.segs[v.tile_seg[gt]];
+  const int t = gt - sg.tile0;
+  const unsigned long long* src = v.keys[level & 1] + sg.key_off;
+  unsigned long long* dst = v.keys[(level & 1) ^ 1] + sg.key_off;
+  const int run = kVoxTile << level;
+  for (int e = tid; e < kVoxTile; e += 256) {
+    const int p = t * kVoxTile + e;
+    if (p >= sg.n) break;
+    const unsigned long long key = src[p];
+    const int r = p / run, sib = r ^ 1;
+    const int sb = sib * run;
+    int dest = p;
+    if (sb < sg.n) {
+      int lo = sb, hi = min(sg.n, sb + run);                                // count of sibling keys < key
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (src[mid] < key) lo = mid + 1; else hi = mid; }
+      dest = (r >> 1) * 2 * run + (p - r * run) + (lo - sb);
+    }
+    dst[dest] = key;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_vox_heads(VoxArgs v) {
+  const int gt = blockIdx.x, tid = threadIdx.x;
+  if (gt >= v.counters[0]) return;
+  const VoxSeg sg = v.segs[v.tile_seg[gt]];
+  const int t = gt - sg.tile0;
+  const unsigned long long* K = v.keys[v.levels & 1] + sg.key_off;
+  int heads = 0;
+  for (int e = tid; e < kVoxTile; e += 256) {
+    const int p = t * kVoxTile + e;
+    if (p < sg.n && (p == 0 || (unsigned)(K[p - 1] >> 32) != (unsigned)(K[p] >> 32))) ++heads;
+  }
+  __shared__ int s_sum;
+  if (tid == 0) s_sum = 0;
+  __syncthreads();
+  for (int d = 32; d > 0; d >>= 1) heads += __shfl_down(heads, d, 64);
+  if ((tid & 63) == 0) atomicAdd(&s_sum, heads);
+  __syncthreads();
+  if (tid == 0) v.tile_heads[gt] = s_sum;
+}
+
+// exclusive prefix of the head counts over all tiles (one 1024-thread workgroup), per-segment output counts
+__global__ __launch_bounds__(1024) void k_vox_scan(VoxArgs v) {
+  const int tid = threadIdx.x;
+  const int n = v.counters[0];
+  __shared__ int s_part[1024];
+  const int per = (n + 1023) / 1024;
+  const int t0 = tid * per, t1 = min(n, t0 + per);
+  int local = 0;
+  for (int t = t0; t < t1; ++t) local += v.tile_heads[t];
+  s_part[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int x = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += x;
+    __syncthreads();
+  }
+  int run = s_part[tid] - local;
+  for (int t = t0; t < t1; ++t) { v.tile_pref[t] = run; run += v.tile_heads[t]; }
+  if (tid == 1023 || t1 == n) v.tile_pref[n] = s_part[1023];
+  __threadfence();
+  __syncthreads();
+  for (int s = tid; s < v.n_segs; s += 1024) {
+    const VoxSeg& sg = v.segs[s];
+    int m = 0;
+    if (sg.ntiles > 0) {
+      int hi = 0;                                                           // prefix at the end of the segment's last tile
+      const int last = sg.tile0 + sg.ntiles;
+      // tile_pref of other threads' ranges is visible after the barrier (same workgroup, global memory)
+      hi = (last >= n) ? s_part[1023] : ((volatile int*)v.tile_pref)[last];
+      m = hi - ((volatile int*)v.tile_pref)[sg.tile0];
+    }
+    if (sg.out_count && !sg.final_count) *sg.out_count = m;
+    if (sg.final_count) *sg.final_count = m;
+  }
+}
+
+// centroids: the head of every voxel run sums its members in key order (= input order) and writes output number `rank`
+__global__ __launch_bounds__(256) void k_vox_emit(VoxArgs v) {
+  const int gt = blockIdx.x, tid = threadIdx.x;
+  if (gt >= v.counters[0]) return;
+  const VoxSeg sg = v.segs[v.tile_seg[gt]];
+  const int t = gt - sg.tile0;
+  const unsigned long long* K = v.keys[v.levels & 1] + sg.key_off;
+  constexpr int PER = kVoxTile / 256;
+  __shared__ int s_scan[256];
+  const int p0 = t * kVoxTile + tid * PER;
+  int heads = 0;
+  unsigned flags = 0;
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int p = p0 + e;
+    if (p < sg.n && (p == 0 || (unsigned)(K[p - 1] >> 32) != (unsigned)(K[p] >> 32))) { ++heads; flags |= 1u << e; }
+  }
+  s_scan[tid] = heads;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int x = tid >= d ? s_scan[tid - d] : 0;
+    __syncthreads();
+    s_scan[tid] += x;
+    __syncthreads();
+  }
+  int rank = v.tile_pref[gt] - v.tile_pref[sg.tile0] + s_scan[tid] - heads;
+#pragma unroll 1
+  for (int e = 0; e < PER; ++e) {
+    if (!(flags & (1u << e))) continue;
+    const int p = p0 + e;
+    const unsigned vi = (unsigned)(K[p] >> 32);
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    int cnt = 0;
+    for (int q = p; q < sg.n; ++q) {
+      const unsigned long long kq = K[q];
+      if ((unsigned)(kq >> 32) != vi) break;
+      const float4 pt = sg.in[(unsigned)kq];
+      sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
+      ++cnt;
+    }
+    const float fc = (float)cnt;
+    sg.out[rank++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+  }
+}
+
+// in-place re-filter of a map cube: copy the centroids from the scratch area back over the cube's segment
+__global__ __launch_bounds__(256) void k_vox_copyback(VoxArgs v) {
+  const int gt = blockIdx.x, tid = threadIdx.x;
+  if (gt >= v.counters[0]) return;
+  const VoxSeg sg = v.segs[v.tile_seg[gt]];
+  if (!sg.final_out) return;
+  const int t = gt - sg.tile0;
+  const int m = v.tile_pref[min(sg.tile0 + sg.ntiles, v.counters[0])] - v.tile_pref[sg.tile0];
+  for (int e = tid; e < kVoxTile; e += 256) { const int i = t * kVoxTile + e; if (i < m) sg.final_out[i] = sg.out[i]; }
+}
+
+// =======================================================================================================
+// kd-tree stand-in over the submap: 1 m cell hash, global counting sort
+// =======================================================================================================
+__global__ __launch_bounds__(256) void k_mapgrid_count(MapArgs a) {
+  const int b = blockIdx.y, cls = blockIdx.z;
+  const MapSeq& ms = a.seq[b];
+  const int n = ms.from_total[cls];
+  const int g0 = blockIdx.x * 1024;
+  if (g0 >= n) return;
+  const int* tab = a.tab + (long long)b * kTabInts;
+  const int H = a.grid_H[cls];
+  int* cnt = a.grid_cnt[cls] + (long long)b * H;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = g0 + k * 256 + threadIdx.x;
+    if (g < n) {
+      const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
+      atomicAdd(&cnt[hash_cell((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (H - 1)], 1);
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_mapgrid_scan(MapArgs a) {
+  const int b = blockIdx.x, cls = blockIdx.y, tid = threadIdx.x;
+  const int H = a.grid_H[cls];
+  int* cnt = a.grid_cnt[cls] + (long long)b * H;
+  int* start = a.grid_start[cls] + (long long)b * (H + 1);
+  __shared__ int part[1024];
+  const int per = H / 1024;
+  int local = 0;
+  for (int k = 0; k < per; ++k) local += cnt[tid * per + k];
+  part[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int x = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += x;
+    __syncthreads();
+  }
+  int run = part[tid] - local;
+  for (int k = 0; k < per; ++k) { const int c = cnt[tid * per + k]; start[tid * per + k] = run; cnt[tid * per + k] = run; run += c; }
+  if (tid == 1023) start[H] = run;
+}
+
+__global__ __launch_bounds__(256) void k_mapgrid_fill(MapArgs a) {
+  const int b = blockIdx.y, cls = blockIdx.z;
+  const MapSeq& ms = a.seq[b];
+  const int n = ms.from_total[cls];
+  const int g0 = blockIdx.x * 1024;
+  if (g0 >= n) return;
+  const int* tab = a.tab + (long long)b * kTabInts;
+  const int H = a.grid_H[cls];
+  int* cur = a.grid_cnt[cls] + (long long)b * H;
+  float4* sorted = a.grid_sorted[cls] + (long long)b * a.pool_cap;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int g = g0 + k * 256 + threadIdx.x;
+    if (g < n) {
+      const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
+      const int pos = atomicAdd(&cur[hash_cell((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (H - 1)], 1);
+      sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(g));
+    }
+  }
+}
+
+// =======================================================================================================
+// data association: exact 5-NN within 1 m, line / plane fit, factor records
+// =======================================================================================================
+namespace {
+
+struct Top5 {
+  float d[5]; int id[5]; float x[5], y[5], z[5];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { d[k] = 3.0e38f; id[k] = 0x7fffffff; x[k] = y[k] = z[k] = 0.f; }
+  }
+  __device__ __forceinline__ void insert(float dd, int ii, float xx, float yy, float zz) {
+    if (!(dd < d[4] || (dd == d[4] && ii < id[4]))) return;
+    d[4] = dd; id[4] = ii; x[4] = xx; y[4] = yy; z[4] = zz;
+#pragma unroll
+    for (int s = 4; s >= 1; --s) {
+      const bool sw = d[s] < d[s - 1] || (d[s] == d[s - 1] && id[s] < id[s - 1]);
+      if (sw) {
+        float tf; int ti;
+        tf = d[s]; d[s] = d[s - 1]; d[s - 1] = tf;
+        ti = id[s]; id[s] = id[s - 1]; id[s - 1] = ti;
+        tf = x[s]; x[s] = x[s - 1]; x[s - 1] = tf;
+        tf = y[s]; y[s] = y[s - 1]; y[s - 1] = tf;
+        tf = z[s]; z[s] = z[s - 1]; z[s - 1] = tf;
+      }
+    }
+  }
+};
+
+// Symmetric 3x3 eigen-decomposition by cyclic Jacobi, standing in for Eigen::SelfAdjointEigenSolver<Matrix3d>
+// (reference src/laserMapping.cpp:605).  The operation sequence is fixed (DESIGN.md "Mapping") so that CPU restatements of it
+// agree bit-for-bit; it is not Eigen's tridiagonal-QL algorithm, results differ from Eigen at the 1e-15 level.
+// Returns ascending eigenvalues in vals and the eigenvector of the LARGEST one in dir (the only one the reference uses, :609).
+__device__ __forceinline__ void sym_eigen3(const double A0[3][3], double vals[3], double dir[3]) {
+  double a[3][3], v[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[i][j] = 0.5 * (A0[i][j] + A0[j][i]);
+  for (int sweep = 0; sweep < 50; ++sweep) {
+    const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+    if (off <= 1e-22 * (fabs(a[0][0]) + fabs(a[1][1]) + fabs(a[2][2]))) break;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = p + 1; q < 3; ++q) {
+        if (a[p][q] == 0.0) continue;
+        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double akp = a[k][p], akq = a[k][q]; a[k][p] = cs * akp - sn * akq; a[k][q] = sn * akp + cs * akq; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double apk = a[p][k], aqk = a[q][k]; a[p][k] = cs * apk - sn * aqk; a[q][k] = sn * apk + cs * aqk; }
+        a[p][q] = 0.0; a[q][p] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const double vkp = v[k][p], vkq = v[k][q]; v[k][p] = cs * vkp - sn * vkq; v[k][q] = sn * vkp + cs * vkq; }
+      }
+  }
+  // ascending order of the diagonal, same exchange sequence as the stand-in (order[] = {0,1,2}; swap when a later one is smaller)
+  double dg[3] = {a[0][0], a[1][1], a[2][2]};
+  double c0[3] = {v[0][0], v[1][0], v[2][0]}, c1[3] = {v[0][1], v[1][1], v[2][1]}, c2[3] = {v[0][2], v[1][2], v[2][2]};
+  auto swp = [&](double& x, double& y, double* cx, double* cy) {
+    const double tv = x; x = y; y = tv;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double tc = cx[k]; cx[k] = cy[k]; cy[k] = tc; }
+  };
+  if (dg[1] < dg[0]) swp(dg[0], dg[1], c0, c1);
+  if (dg[2] < dg[0]) swp(dg[0], dg[2], c0, c2);
+  if (dg[2] < dg[1]) swp(dg[1], dg[2], c1, c2);
+  vals[0] = dg[0]; vals[1] = dg[1]; vals[2] = dg[2];
+  dir[0] = c2[0]; dir[1] = c2[1]; dir[2] = c2[2];
+}
+
+// min |A x - b| for the 5 x 3 plane fit: Householder QR with column pivoting, standing in for colPivHouseholderQr().solve()
+// (reference src/laserMapping.cpp:663); fixed operation sequence, see above.
+__device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[3]) {
+  int perm[3] = {0, 1, 2};
+  int rank = 0;
+  double maxnorm0 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (rank != k) break;
+    int piv = k;
+    double best = -1.0;
+#pragma unroll
+    for (int j = k; j < 3; ++j) {
+      double s = 0.0;
+#pragma unroll
+      for (int i = k; i < 5; ++i) s += a[i][j] * a[i][j];
+      if (s > best) { best = s; piv = j; }
+    }
+    if (k == 0) maxnorm0 = best;
+    if (!(best > maxnorm0 * 1e-30)) break;
+#pragma unroll
+    for (int j = k + 1; j < 3; ++j) {
+      if (piv == j) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { const double tv = a[i][k]; a[i][k] = a[i][j]; a[i][j] = tv; }
+        const int tp = perm[k]; perm[k] = perm[j]; perm[j] = tp;
+      }
+    }
+    const double alpha = (a[k][k] > 0.0 ? -1.0 : 1.0) * sqrt(best);
+    double v[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = i < k ? 0.0 : a[i][k];
+    v[k] -= alpha;
+    double vv = 0.0;
+#pragma unroll
+    for (int i = k; i < 5; ++i) vv += v[i] * v[i];
+    if (vv > 0.0) {
+#pragma unroll
+      for (int j = k; j < 3; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = k; i < 5; ++i) s += v[i] * a[i][j];
+        s = 2.0 * s / vv;
+#pragma unroll
+        for (int i = k; i < 5; ++i) a[i][j] -= s * v[i];
+      }
+      double s = 0.0;
+#pragma unroll
+      for (int i = k; i < 5; ++i) s += v[i] * b[i];
+      s = 2.0 * s / vv;
+#pragma unroll
+      for (int i = k; i < 5; ++i) b[i] -= s * v[i];
+    }
+    ++rank;
+  }
+  double y[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 2; k >= 0; --k) {
+    if (k < rank) {
+      double s = b[k];
+#pragma unroll
+      for (int j = k + 1; j < 3; ++j) if (j < rank) s -= a[k][j] * y[j];
+      y[k] = s / a[k][k];
+    }
+  }
+  x[0] = x[1] = x[2] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) if (perm[k] == j) x[j] = y[k];
+}
+
+}  // namespace
+
+template <int CLS>
+__global__ __launch_bounds__(256) void k_map_associate(MapArgs a, int iter) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  MapSeq& ms = a.seq[b];
+  const int n = ms.n_stack[CLS];
+  if (i >= n) return;
+  const long long sb = (long long)b * (CLS == 0 ? a.R * 120 : a.cap);
+  const float4 ori = a.stack[CLS][sb + i];                                 // pointOri (:578, :644)
+  bool valid = false;
+  double ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0}, rd = 0.0;
+  if (ms.gate) {
+    double par[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
+    const float4 sel = associate_to_map(ori, par);                         // pointSel (:580, :646)
+    const int H = a.grid_H[CLS];
+    const int* start = a.grid_start[CLS] + (long long)b * (H + 1);
+    const float4* sorted = a.grid_sorted[CLS] + (long long)b * a.pool_cap;
+    const int cx = (int)floorf(sel.x), cy = (int)floorf(sel.y), cz = (int)floorf(sel.z);
+    Top5 top;
+    top.init();
+    // every point closer than 1 m lies in the 3x3x3 block of 1 m cells around the query; the reference discards the
+    // result unless the 5th neighbour is closer than 1 m (:582, :650), so this bounded search is an exact stand-in
+    for (int c = 0; c < 27; ++c) {
+      const int ex = cx + c % 3 - 1, ey = cy + (c / 3) % 3 - 1, ez = cz + c / 9 - 1;
+      const unsigned h = hash_cell(ex, ey, ez) & (unsigned)(H - 1);
+      const int s0 = start[h], s1 = start[h + 1];
+      for (int k = s0; k < s1; ++k) {
+        const float4 p = sorted[k];
+        if ((int)floorf(p.x) != ex || (int)floorf(p.y) != ey || (int)floorf(p.z) != ez) continue;   // another cell hashed into this bucket
+        const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
+        const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;               // FLANN L2_Simple, f32
+        if (d < 1.0f) top.insert(d, __float_as_int(p.w), p.x, p.y, p.z);
+      }
+    }
+    if (top.d[4] < 1.0f) {                                                 // pointSearchSqDis[4] < 1.0
+      if (CLS == 0) {
+        double cxs = 0.0, cys = 0.0, czs = 0.0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { cxs = cxs + (double)top.x[j]; cys = cys + (double)top.y[j]; czs = czs + (double)top.z[j]; }
+        const double ctr[3] = {cxs / 5.0, cys / 5.0, czs / 5.0};
+        double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const double zm[3] = {(double)top.x[j] - ctr[0], (double)top.y[j] - ctr[1], (double)top.z[j] - ctr[2]};
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) cov[r][c] = cov[r][c] + zm[r] * zm[c];
+        }
+        double vals[3], dir[3];
+        sym_eigen3(cov, vals, dir);
+        if (vals[2] > 3 * vals[1]) {                                       // :611
+          valid = true;
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { ra[k] = 0.1 * dir[k] + ctr[k]; rb[k] = -0.1 * dir[k] + ctr[k]; }
+        }
+      } else {
+        double A[5][3], B[5] = {-1, -1, -1, -1, -1}, x[3];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) { A[j][0] = top.x[j]; A[j][1] = top.y[j]; A[j][2] = top.z[j]; }
+        lstsq_5x3(A, B, x);
+        const double len = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        const double d = 1 / len;                                          // negative_OA_dot_norm (:664)
+        const double nx = x[0] / len, ny = x[1] / len, nz = x[2] / len;
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          if (fabs(nx * (double)top.x[j] + ny * (double)top.y[j] + nz * (double)top.z[j] + d) > 0.2) ok = false;   // :672-678
+        if (ok) { valid = true; ra[0] = nx; ra[1] = ny; ra[2] = nz; rd = d; }
+      }
+    }
+  }
+  if (CLS == 0) {
+    MapEdgeRec e;
+    e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { e.a[k] = ra[k]; e.b[k] = rb[k]; }
+    e.valid = valid ? 1 : 0; e.pad = 0;
+    a.edges[(long long)b * a.R * 120 + i] = e;
+  } else {
+    MapNormRec e;
+    e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) e.n[k] = ra[k];
+    e.d = rd; e.valid = valid ? 1 : 0; e.pad = 0;
+    a.norms[(long long)b * a.cap + i] = e;
+  }
+  (void)iter;
+}
+
+// =======================================================================================================
+// solve
+// =======================================================================================================
+template <bool WITH_JAC>
+__device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const double t[3], double* acc, int* n_edge, int* n_norm) {
+  const int tid = threadIdx.x;
+  const MapSeq& ms = a.seq[b];
+  const MapEdgeRec* E = a.edges + (long long)b * a.R * 120;
+  const MapNormRec* P = a.norms + (long long)b * a.cap;
+  int ne = 0, np = 0;
+  for (int i = tid; i < ms.n_stack[0]; i += 256) {
+    const MapEdgeRec e = E[i];
+    if (!e.valid) continue;
+    ++ne;
+    double rcp[3];
+    quat_rotate(q, e.cp[0], e.cp[1], e.cp[2], rcp);
+    const double lp[3] = {rcp[0] + t[0], rcp[1] + t[1], rcp[2] + t[2]};
+    const double dex = e.a[0] - e.b[0], dey = e.a[1] - e.b[1], dez = e.a[2] - e.b[2];
+    const double inv = 1.0 / sqrt(dex * dex + dey * dey + dez * dez);
+    const double ux = lp[0] - e.a[0], uy = lp[1] - e.a[1], uz = lp[2] - e.a[2], vx = lp[0] - e.b[0], vy = lp[1] - e.b[1], vz = lp[2] - e.b[2];
+    const double r0 = (uy * vz - uz * vy) * inv, r1 = (uz * vx - ux * vz) * inv, r2 = (ux * vy - uy * vx) * inv;
+    double rho0, rho1;
+    huber(r0 * r0 + r1 * r1 + r2 * r2, &rho0, &rho1);
+    acc[27] += 0.5 * rho0;
+    if (WITH_JAC) {
+      const double wx = -dex * inv, wy = -dey * inv, wz = -dez * inv;
+      const double A[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+      const double Bm[3][3] = {{0, 2 * rcp[2], -2 * rcp[1]}, {-2 * rcp[2], 0, 2 * rcp[0]}, {2 * rcp[1], -2 * rcp[0], 0}};
+      const double rr[3] = {r0, r1, r2};
+#pragma unroll
+      for (int row = 0; row < 3; ++row) {
+        double J[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          J[c] = A[row][0] * Bm[0][c] + A[row][1] * Bm[1][c] + A[row][2] * Bm[2][c];
+          J[3 + c] = A[row][c];
+        }
+        add_row(acc, J, rr[row], rho1);
+      }
+    }
+  }
+  for (int i = tid; i < ms.n_stack[1]; i += 256) {
+    const MapNormRec p = P[i];
+    if (!p.valid) continue;
+    ++np;
+    double rcp[3];
+    quat_rotate(q, p.cp[0], p.cp[1], p.cp[2], rcp);
+    // LidarPlaneNormFactor (reference src/lidarFactor.hpp:116-123): r = n . (q cp + t) + d
+    const double r = (p.n[0] * (rcp[0] + t[0]) + p.n[1] * (rcp[1] + t[1]) + p.n[2] * (rcp[2] + t[2])) + p.d;
+    double rho0, rho1;
+    huber(r * r, &rho0, &rho1);
+    acc[27] += 0.5 * rho0;
+    if (WITH_JAC) {
+      const double J[6] = {2.0 * (p.n[2] * rcp[1] - p.n[1] * rcp[2]), 2.0 * (p.n[0] * rcp[2] - p.n[2] * rcp[0]), 2.0 * (p.n[1] * rcp[0] - p.n[0] * rcp[1]),
+                           p.n[0], p.n[1], p.n[2]};
+      add_row(acc, J, r, rho1);
+    }
+  }
+  *n_edge = ne;
+  *n_norm = np;
+}
+
+__global__ __launch_bounds__(256) void k_map_solve(MapArgs a, int iter, int last) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ double s_red[4 * 28];
+  MapSeq& ms = a.seq[b];
+  double q[4] = {ms.par[0], ms.par[1], ms.par[2], ms.par[3]};
+  double t[3] = {ms.par[4], ms.par[5], ms.par[6]};
+  const LmResult lm = lm_solve_block([&](bool with_jac, const double* qq, const double* tt, double* acc, int* ne, int* np) {
+    if (with_jac) map_evaluate<true>(a, b, qq, tt, acc, ne, np); else map_evaluate<false>(a, b, qq, tt, acc, ne, np);
+  }, q, t, a.lm_max_iterations, s_red);
+  if (tid == 0) {
+    for (int k = 0; k < 4; ++k) ms.par[k] = q[k];
+    for (int k = 0; k < 3; ++k) ms.par[4 + k] = t[k];
+    ms.factor_num[iter][0] = lm.n_a;
+    ms.factor_num[iter][1] = lm.n_b;
+    ms.lm_iterations[iter] = lm.iterations;
+    ms.lm_termination[iter] = lm.termination;
+    if (last) {                                                              // transformUpdate (:148-152)
+      const double qo[4] = {ms.q_wodom[0], ms.q_wodom[1], ms.q_wodom[2], ms.q_wodom[3]};
+      const double n2 = qo[0] * qo[0] + qo[1] * qo[1] + qo[2] * qo[2] + qo[3] * qo[3];
+      const double inv[4] = {-qo[0] / n2, -qo[1] / n2, -qo[2] / n2, qo[3] / n2};        // Eigen inverse(): conjugate / squaredNorm
+      double qm[4], rt[3];
+      quat_mul(q, inv, qm);
+      quat_rotate(qm, ms.t_wodom[0], ms.t_wodom[1], ms.t_wodom[2], rt);
+      for (int k = 0; k < 4; ++k) ms.q_wmap_wodom[k] = qm[k];
+      for (int k = 0; k < 3; ++k) ms.t_wmap_wodom[k] = t[k] - rt[k];
+      ms.frame_count += 1;
+    }
+  }
+}
+
+// =======================================================================================================
+// map insertion (:737-783)
+// =======================================================================================================
+__global__ __launch_bounds__(256) void k_map_cubeid(MapArgs a) {
+  const int b = blockIdx.y, cls = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+  const MapSeq& ms = a.seq[b];
+  if (i >= ms.n_stack[cls]) return;
+  const long long sb = (long long)b * (cls == 0 ? a.R * 120 : a.cap);
+  double par[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
+  const float4 w = associate_to_map(a.stack[cls][sb + i], par);
+  const int ci = cube_coord((double)w.x, ms.cen[0]), cj = cube_coord((double)w.y, ms.cen[1]), ck = cube_coord((double)w.z, ms.cen[2]);
+  int id = -1;
+  if (ci >= 0 && ci < kMapW && cj >= 0 && cj < kMapH && ck >= 0 && ck < kMapD) {
+    id = ci + kMapW * cj + kMapW * kMapH * ck;
+    atomicAdd(&a.addcnt[((long long)b * 2 + cls) * kMapCubes + id], 1);
+  }
+  a.stack_world[cls][sb + i] = w;
+  a.stack_cube[cls][sb + i] = id;
+}
+
+// capacity: a cube that would overflow its segment moves to a fresh one of twice the needed size (bump allocation from the
+// class pool; the old segment is abandoned).  Then the append cursor of every touched cube is published.
+__global__ __launch_bounds__(256) void k_map_reserve(MapArgs a) {
+  const int b = blockIdx.x, cls = blockIdx.y, tid = threadIdx.x;
+  CubeDesc* T = cube_table(a, b, cls);
+  int* add = a.addcnt + ((long long)b * 2 + cls) * kMapCubes;
+  int* cur = a.cursor + ((long long)b * 2 + cls) * kMapCubes;
+  float4* pool = a.pool[cls] + (long long)b * a.pool_cap;
+  MapSeq& ms = a.seq[b];
+  __shared__ int s_n;
+  __shared__ int s_list[256][4];   // cube, old offset, new offset, count   (moves of this round)
+  for (int base = 0; base < kMapCubes; base += 256) {
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    const int c = base + tid;
+    if (c < kMapCubes) {
+      const int ad = add[c];
+      if (ad > 0) {
+        CubeDesc d = T[c];
+        if (d.cnt + ad > d.cap) {
+          int want = 2 * (d.cnt + ad);
+          if (want < 256) want = 256;
+          const int off = atomicAdd(&ms.pool_used[cls], want);
+          if (off + want > a.pool_cap) {
+            atomicOr(&ms.err, kMapErrPool);
+            add[c] = -1;                                                     // the scatter pass skips this cube
+          } else {
+            const int k = atomicAdd(&s_n, 1);
+            s_list[k][0] = c; s_list[k][1] = d.off; s_list[k][2] = off; s_list[k][3] = d.cnt;
+            d.off = off; d.cap = want;
+            T[c] = d;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int nmove = s_n;
+    for (int k = 0; k < nmove; ++k)
+      for (int i = tid; i < s_list[k][3]; i += 256) pool[s_list[k][2] + i] = pool[s_list[k][1] + i];
+    __syncthreads();
+    if (c < kMapCubes) {
+      const int ad = add[c];
+      cur[c] = T[c].cnt;
+      if (ad > 0) T[c].cnt += ad;
+    }
+    __syncthreads();
+  }
+}
+
+// stable append: one wave per (sequence, class) walks the stack in order, 64 points a step
+__global__ __launch_bounds__(64) void k_map_scatter(MapArgs a) {
+  const int b = blockIdx.x, cls = blockIdx.y, lane = threadIdx.x;
+  const MapSeq& ms = a.seq[b];
+  const int n = ms.n_stack[cls];
+  const CubeDesc* T = cube_table(a, b, cls);
+  int* add = a.addcnt + ((long long)b * 2 + cls) * kMapCubes;
+  const int* cur = a.cursor + ((long long)b * 2 + cls) * kMapCubes;
+  float4* pool = a.pool[cls] + (long long)b * a.pool_cap;
+  const long long sb = (long long)b * (cls == 0 ? a.R * 120 : a.cap);
+  __shared__ int s_cur[kMapCubes];
+  for (int c = lane; c < kMapCubes; c += 64) s_cur[c] = add[c] < 0 ? -1 : cur[c];
+  __syncthreads();
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    int id = -1;
+    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) { id = a.stack_cube[cls][sb + i]; w = a.stack_world[cls][sb + i]; }
+    unsigned long long todo = __ballot(id >= 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int c = __shfl(id, leader, 64);
+      const unsigned long long same = __ballot(id == c);
+      const int start = s_cur[c];
+      if (id == c && start >= 0) pool[T[c].off + start + __popcll(same & ((1ull << lane) - 1ull))] = w;
+      __syncthreads();
+      if (lane == leader && start >= 0) s_cur[c] = start + __popcll(same);
+      __syncthreads();
+      todo &= ~same;
+    }
+  }
+  __syncthreads();
+  for (int c = lane; c < kMapCubes; c += 64) add[c] = 0;                     // ready for the next frame
+}
+
+__global__ __launch_bounds__(256) void k_map_register(MapArgs a) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.meta[b].n_cloud) return;
+  const MapSeq& ms = a.seq[b];
+  double par[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
+  a.registered[(long long)b * a.cap + i] = associate_to_map(a.full[(long long)b * a.cap + i], par);
+}
+
+// =======================================================================================================
+// launchers
+// =======================================================================================================
+void launch_map_begin(const MapArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_map_begin, dim3(a.B), dim3(256), 0, s, a); }
+void launch_map_stack_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_stack_segments, dim3((a.B * 2 + 255) / 256), dim3(256), 0, s, a, v);
+}
+void launch_map_cube_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_cube_segments, dim3((a.B * 2 * kMapValidMax + 255) / 256), dim3(256), 0, s, a, v);
+}
+void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
+  hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(1024), 0, s, v);
+  hipLaunchKernelGGL(k_vox_bbox, dim3(tile_bound), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(k_vox_keys_sort, dim3(tile_bound), dim3(256), 0, s, v);
+  for (int level = 0; level < v.levels; ++level) hipLaunchKernelGGL(k_vox_merge, dim3(tile_bound), dim3(256), 0, s, v, level);
+  hipLaunchKernelGGL(k_vox_heads, dim3(tile_bound), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, s, v);
+  hipLaunchKernelGGL(k_vox_emit, dim3(tile_bound), dim3(256), 0, s, v);
+  hipLaunchKernelGGL(k_vox_copyback, dim3(tile_bound), dim3(256), 0, s, v);
+}
+void launch_map_grid(const MapArgs& a, hipStream_t s) {
+  for (int cls = 0; cls < 2; ++cls) (void)hipMemsetAsync(a.grid_cnt[cls], 0, sizeof(int) * (size_t)a.B * a.grid_H[cls], s);
+  const dim3 g((a.pool_cap + 1023) / 1024, a.B, 2);
+  hipLaunchKernelGGL(k_mapgrid_count, g, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_mapgrid_scan, dim3(a.B, 2), dim3(1024), 0, s, a);
+  hipLaunchKernelGGL(k_mapgrid_fill, g, dim3(256), 0, s, a);
+}
+void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_associate<0>, dim3((a.R * 120 + 255) / 256, a.B), dim3(256), 0, s, a, iter);
+  hipLaunchKernelGGL(k_map_associate<1>, dim3((a.cap + 255) / 256, a.B), dim3(256), 0, s, a, iter);
+}
+void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) { hipLaunchKernelGGL(k_map_solve, dim3(a.B), dim3(256), 0, s, a, iter, last ? 1 : 0); }
+void launch_map_insert(const MapArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_cubeid, dim3((a.cap + 255) / 256, a.B, 2), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_reserve, dim3(a.B, 2), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_scatter, dim3(a.B, 2), dim3(64), 0, s, a);
+}
+void launch_map_register(const MapArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_map_register, dim3((a.cap + 255) / 256, a.B), dim3(256), 0, s, a); }
+
+}  // namespace aloam

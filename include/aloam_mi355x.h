@@ -91,6 +91,26 @@ int aloam_odometry_step(aloam_ctx* ctx);                             /* asynchro
 /* ---- throughput entry: stage 1 + stage 2 for one sweep of every sequence, asynchronous -------------------- */
 int aloam_process_device(aloam_ctx* ctx, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes);
 
+/* ---- stage 3: scan-to-map refinement, body of process() (reference src/laserMapping.cpp:231-893), no frame dropping ---- */
+/* Replaces the node's globals (cube arrays laserCloudCornerArray / SurfArray[4851], q_wmap_wodom, t_wmap_wodom, `parameters`,
+ * laserCloudCen*; src/laserMapping.cpp:72-116) and reads the launch parameters mapping_line_resolution / mapping_plane_resolution
+ * (:898-905).  pool_points = capacity of the device-resident map per sequence and feature class.  Call once, before the first step. */
+int aloam_mapping_enable(aloam_ctx* ctx, float mapping_line_resolution, float mapping_plane_resolution, int pool_points);
+/* One frame for every sequence, asynchronous.  Consumes what the odometry node publishes for the frame — /laser_cloud_corner_last,
+ * /laser_cloud_surf_last, /velodyne_cloud_3, /laser_odom_to_init (src/laserOdometry.cpp:508-591) — straight from the context
+ * (call after aloam_odometry_step / aloam_process_device), or as injected through aloam_set_last / aloam_set_full_cloud / aloam_set_state. */
+int aloam_mapping_step(aloam_ctx* ctx);
+int aloam_set_full_cloud(aloam_ctx* ctx, int seq, const float* cloud_xyzw, int n);          /* /velodyne_cloud_3 (src/laserMapping.cpp:189-194) */
+/* /aft_mapped_to_init pose = q_w_curr, t_w_curr (src/laserMapping.cpp:851-863) and the map<-odom correction (:148-152) */
+int aloam_get_map_pose(aloam_ctx* ctx, int seq, double q_w_curr[4], double t_w_curr[3], double q_wmap_wodom[4], double t_wmap_wodom[3]);
+/* laserCloudCenWidth/Height/Depth, frameCount, submap sizes (corner, surf), stack sizes (corner, surf), factors per iteration
+ * (corner[2], surf[2]), LM iterations[2], termination[2] */
+int aloam_get_map_info(aloam_ctx* ctx, int seq, int out[16]);
+int aloam_map_cube_counts(aloam_ctx* ctx, int seq, int feature_class, int* out_4851);      /* points per cube of the 21 x 21 x 11 window */
+int aloam_get_map_cube(aloam_ctx* ctx, int seq, int feature_class, int cube, float* out_xyzw, int cap_points);   /* laserCloud*Array[cube] */
+enum { ALOAM_MAP_REGISTERED = 2, ALOAM_MAP_CORNER_STACK = 3, ALOAM_MAP_SURF_STACK = 4 };    /* /velodyne_cloud_registered (:836-846); laserCloud*Stack (:542-550) */
+int aloam_get_map_cloud(aloam_ctx* ctx, int seq, int which, float* out_xyzw, int cap_points);
+
 /* ---- results (each synchronises the stream) ---------------------------------------------------------------- */
 int aloam_cloud_size(aloam_ctx* ctx, int seq, int which);            /* replaces cloud.points.size()            */
 int aloam_get_cloud(aloam_ctx* ctx, int seq, int which, float* out_xyzw, int cap_points);  /* what pcl::toROSMsg publishes (src/scanRegistration.cpp:413-441, src/laserOdometry.cpp:574-590) */
