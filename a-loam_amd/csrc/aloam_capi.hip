@@ -24,7 +24,8 @@ enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_F
                 K_MAP_VOXEL_CUBES, K_MAP_REGISTER, K_COUNT };
 const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_classify", "k_ring_offsets", "k_scatter", "k_ring_features",
                                      "k_compact_features", "k_build_grids", "k_associate[corner]", "k_associate[plane]",
-                                     "k_solve", "k_advance"};
+                                     "k_solve", "k_advance", "map_begin", "map_voxel[stacks]", "map_grid", "map_associate", "map_solve",
+                                     "map_insert", "map_voxel[cubes]", "map_register"};
 struct ProfRec { int kernel; hipEvent_t e0, e1; };
 }  // namespace
 

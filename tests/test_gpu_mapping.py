@@ -104,3 +104,35 @@ def test_mapping_window_shift_and_growth(O, binding, lm_iters):
                 _compare_maps(gpu.map_cubes(cls, seq), o.map_cubes(cls), (k, seq, cls), exact=lm_iters == 0)
     assert gpu.map_info(0)["cenW"] != 10 and max(len(v) for v in gpu.map_cubes(1, 1).values()) > 2048
     gpu.close()
+
+
+@pytest.mark.parametrize("name,frames,kw,res", [("VLP-16", 5, {"columns": 900}, (0.2, 0.4)), ("HDL-64", 4, {"columns": 1024}, (0.4, 0.8))])
+def test_full_pipeline_registration_odometry_mapping(O, binding, sequence, name, frames, kw, res):
+    """Raw sweeps in, refined map poses out: scan registration -> odometry -> mapping chained inside one context (nothing
+    leaves HBM between the stages), against the oracle chained the same way."""
+    scans, R, t, model = sequence(name, frames, seed=31, **kw)
+    orc = O.Oracle(n_scans=model.n_scans, min_range=model.min_range)
+    orc.map_config(*res)
+    gpu = binding.Aloam(n_scans=model.n_scans, min_range=model.min_range, max_points=max(len(s) for s in scans) + 64)
+    gpu.mapping_enable(*res, pool_points=131072)
+    for k, x in enumerate(scans):
+        orc.scan_register(x)
+        po = orc.odometry_step()
+        pm = orc.mapping_step(po["q_w"], po["t_w"], orc.cloud(O.CLOUD_CORNER_LAST), orc.cloud(O.CLOUD_SURF_LAST), orc.cloud(O.CLOUD_FULL))
+        gpu.scan_register(x)
+        gpu.odometry_step()
+        gpu.mapping_step()
+        gpu.synchronize()
+        pg, mg = gpu.pose(), gpu.map_pose()
+        assert np.abs(po["t_w"] - pg["t_w"]).max() < 1e-9
+        for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+            assert np.abs(pm[key] - mg[key]).max() < 1e-8, (name, k, key, pm[key], mg[key])
+        io, ig = orc.map_info(), gpu.map_info()
+        for key in ("from_map_corner", "from_map_surf", "corner_stack", "surf_stack", "corner_num1", "surf_num1"):
+            assert io[key] == ig[key], (name, k, key, io, ig)
+        for cls in (0, 1):
+            _compare_maps(gpu.map_cubes(cls), orc.map_cubes(cls), (name, k, cls), exact=False)
+    # the refinement pulls the pose towards the synthetic ground truth at least as well as the odometry alone
+    gt = R[0].T @ (t[frames - 1] - t[0])
+    assert np.linalg.norm(mg["t_w"] - gt) <= np.linalg.norm(pg["t_w"] - gt) + 0.05
+    gpu.close()
