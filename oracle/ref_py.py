@@ -62,7 +62,7 @@ class _Reader:
         return self.o == len(self.b)
 
 
-def scan_registration(scans, n_scans, min_range):
+def scan_registration(scans, n_scans, min_range, exe=None):
     """scans: list of (n, 4) float32 arrays -> list of dicts with the five published clouds + curvature / label / picked."""
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
@@ -70,7 +70,7 @@ def scan_registration(scans, n_scans, min_range):
             f.write(struct.pack("<i", len(scans)))
             for s in scans:
                 _write_cloud(f, s)
-        r = subprocess.run([os.path.join(REF_DIR, "ref_scan_registration"), str(int(n_scans)), repr(float(min_range)), fin, fout],
+        r = subprocess.run([exe or os.path.join(REF_DIR, "ref_scan_registration"), str(int(n_scans)), repr(float(min_range)), fin, fout],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"ref_scan_registration failed ({r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
@@ -87,7 +87,7 @@ def scan_registration(scans, n_scans, min_range):
         return out
 
 
-def laser_odometry(frames):
+def laser_odometry(frames, exe=None, exe_args=()):
     """frames: list of dicts with sharp / less_sharp / flat / less_flat / cloud -> list of dicts (q_w, t_w, q_lc, t_lc,
     corner_corr, plane_corr, corner_last, surf_last), one per frame, from ONE run of the node (state carries over)."""
     with tempfile.TemporaryDirectory() as d:
@@ -97,7 +97,7 @@ def laser_odometry(frames):
             for fr in frames:
                 for k in ("sharp", "less_sharp", "flat", "less_flat", "cloud"):
                     _write_cloud(f, fr[k])
-        r = subprocess.run([os.path.join(REF_DIR, "ref_laser_odometry"), fin, fout], capture_output=True, text=True)
+        r = subprocess.run([exe or os.path.join(REF_DIR, "ref_laser_odometry"), *[str(a) for a in exe_args], fin, fout], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"ref_laser_odometry failed ({r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
         rd = _Reader(fout)
@@ -111,7 +111,7 @@ def laser_odometry(frames):
         return out
 
 
-def laser_mapping(frames, line_res, plane_res, dump_map=True):
+def laser_mapping(frames, line_res, plane_res, dump_map=True, exe=None, exe_args=()):
     """frames: list of dicts with q_w / t_w (odometry pose), corner_last, surf_last, cloud (full resolution) -> list of dicts
     (q_w, t_w = refined pose, q_wmap_wodom, t_wmap_wodom, registered, cen, corner_map {cube: pts}, surf_map {cube: pts})."""
     with tempfile.TemporaryDirectory() as d:
@@ -122,7 +122,7 @@ def laser_mapping(frames, line_res, plane_res, dump_map=True):
                 f.write(np.concatenate([np.asarray(fr["q_w"], np.float64), np.asarray(fr["t_w"], np.float64)]).tobytes())
                 for k in ("corner_last", "surf_last", "cloud"):
                     _write_cloud(f, fr[k])
-        r = subprocess.run([os.path.join(REF_DIR, "ref_laser_mapping"), repr(float(line_res)), repr(float(plane_res)), fin, fout],
+        r = subprocess.run([exe or os.path.join(REF_DIR, "ref_laser_mapping"), *[str(a) for a in exe_args], repr(float(line_res)), repr(float(plane_res)), fin, fout],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"ref_laser_mapping failed ({r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
