@@ -51,6 +51,8 @@ struct aloam_ctx {
   OdomState* d_state = nullptr;
   float4* d_grid_sorted3[2] = {nullptr, nullptr}; float4* d_grid_sorted2[2] = {nullptr, nullptr};
   int* d_grid_start3[2] = {nullptr, nullptr}; int* d_grid_start2[2] = {nullptr, nullptr};
+  float4* d_grid_sorted3c[2] = {nullptr, nullptr}; float4* d_grid_sorted2c[2] = {nullptr, nullptr};   // coarse levels
+  int* d_grid_start3c[2] = {nullptr, nullptr}; int* d_grid_start2c[2] = {nullptr, nullptr};
   int* d_grid_first_ge[2] = {nullptr, nullptr}; int* d_grid_last_le[2] = {nullptr, nullptr}; int* d_grid_flags[2] = {nullptr, nullptr};
   int grid_H[2] = {4096, 16384};
   bool grids_valid = false;          // the grids describe the current "last" clouds
@@ -144,6 +146,8 @@ OdomArgs odom_args(aloam_ctx* c) {
   a.corner_last = c->d_less_sharp[1 - c->cur]; a.surf_last = c->d_less_flat[1 - c->cur];
   for (int k = 0; k < 2; ++k) {
     a.grid_sorted3[k] = c->d_grid_sorted3[k]; a.grid_sorted2[k] = c->d_grid_sorted2[k]; a.grid_start3[k] = c->d_grid_start3[k];
+    a.grid_sorted3c[k] = c->d_grid_sorted3c[k]; a.grid_sorted2c[k] = c->d_grid_sorted2c[k]; a.grid_start3c[k] = c->d_grid_start3c[k];
+    a.grid_start2c[k] = c->d_grid_start2c[k];
     a.grid_start2[k] = c->d_grid_start2[k]; a.grid_first_ge[k] = c->d_grid_first_ge[k]; a.grid_last_le[k] = c->d_grid_last_le[k];
     a.grid_flags[k] = c->d_grid_flags[k];
   }
@@ -259,6 +263,10 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
     if ((rc = dmalloc(c, &c->d_grid_sorted2[k], B * per))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_start3[k], B * (c->grid_H[k] + 1)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_start2[k], B * (c->grid_H[k] + 1)))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_sorted3c[k], B * per))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_sorted2c[k], B * per))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_start3c[k], B * (c->grid_H[k] + 1)))) return rc;
+    if ((rc = dmalloc(c, &c->d_grid_start2c[k], B * (c->grid_H[k] + 1)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_first_ge[k], B * (R + 8)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_last_le[k], B * (R + 8)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_flags[k], B * 4))) return rc;
@@ -284,7 +292,8 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
                   c->d_grid_start2[0], c->d_grid_start2[1], c->d_grid_first_ge[0], c->d_grid_first_ge[1], c->d_grid_last_le[0], c->d_grid_last_le[1],
-                  c->d_grid_flags[0], c->d_grid_flags[1],
+                  c->d_grid_flags[0], c->d_grid_flags[1], c->d_grid_sorted3c[0], c->d_grid_sorted3c[1], c->d_grid_sorted2c[0], c->d_grid_sorted2c[1],
+                  c->d_grid_start3c[0], c->d_grid_start3c[1], c->d_grid_start2c[0], c->d_grid_start2c[1],
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
                   c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,

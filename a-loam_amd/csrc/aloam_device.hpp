@@ -88,6 +88,10 @@ struct OdomArgs {
   float4* grid_sorted2[2];   //                          entries bucketed by (ix,iy,ring key)
   int* grid_start3[2];       // [B][H+1]
   int* grid_start2[2];       // [B][H+1]
+  float4* grid_sorted3c[2];  // coarse levels of the same two grids: they bound the search of far queries
+  float4* grid_sorted2c[2];
+  int* grid_start3c[2];      // [B][H+1]
+  int* grid_start2c[2];      // [B][H+1]
   int* grid_first_ge[2];     // [B][R+8]
   int* grid_last_le[2];      // [B][R+8]
   int* grid_flags[2];        // [B][4]   flags[0] != 0: cloud not ring-sorted / out of range -> literal brute-force path
@@ -101,8 +105,8 @@ struct OdomArgs {
 
 struct GridView {
   int H;
-  float4 *sorted3, *sorted2;
-  int *start3, *start2, *first_ge, *last_le, *flags;
+  float4 *sorted3, *sorted2, *sorted3c, *sorted2c;
+  int *start3, *start2, *start3c, *start2c, *first_ge, *last_le, *flags;
 };
 __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int which) {
   GridView g;
@@ -112,6 +116,10 @@ __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int whic
   g.sorted2 = a.grid_sorted2[which] + b * per;
   g.start3 = a.grid_start3[which] + (long long)b * (g.H + 1);
   g.start2 = a.grid_start2[which] + (long long)b * (g.H + 1);
+  g.sorted3c = a.grid_sorted3c[which] + b * per;
+  g.sorted2c = a.grid_sorted2c[which] + b * per;
+  g.start3c = a.grid_start3c[which] + (long long)b * (g.H + 1);
+  g.start2c = a.grid_start2c[which] + (long long)b * (g.H + 1);
   g.first_ge = a.grid_first_ge[which] + (long long)b * (a.R + 8);
   g.last_le = a.grid_last_le[which] + (long long)b * (a.R + 8);
   g.flags = a.grid_flags[which] + b * 4;

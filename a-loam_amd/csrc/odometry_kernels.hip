@@ -46,6 +46,10 @@ __device__ __forceinline__ float4 transform_to_start(const float4& p, const Odom
 // ring-sorted the way scan registration emits it; clouds that are not (possible through aloam_set_last) and
 // clouds with huge coordinates are flagged and served by the literal brute-force path instead.
 constexpr float kCell3Surf = 0.5f, kCell3Corner = 1.0f, kCell2 = 1.0f;
+// Coarse levels: a query whose neighbour is not inside the first block of fine cells continues on cells four times as large
+// (3-D) / on 5.25 m cells (ring grid: one 3x3 block then covers the whole DISTANCE_SQ_THRESHOLD = 5 m radius), so the work
+// of a far query is bounded by a few dozen bucket look-ups instead of growing with the cube of the radius.
+constexpr float kCell3CoarseFactor = 4.0f, kCell2Coarse = 5.25f;
 constexpr unsigned kIdxMask = (1u << 20) - 1u;
 __device__ __forceinline__ float cell3_of(int which) { return which == 0 ? kCell3Corner : kCell3Surf; }
 
@@ -88,17 +92,19 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
     g.flags[0] = is_bad;
   }
   if (is_bad) return;
-  for (int pass = 0; pass < 2; ++pass) {          // 0: G3, 1: G2
-    const float inv = pass == 0 ? 1.0f / cell3_of(which) : 1.0f / kCell2;
-    int* start = pass == 0 ? g.start3 : g.start2;
-    float4* sorted = pass == 0 ? g.sorted3 : g.sorted2;
+  for (int pass = 0; pass < 4; ++pass) {          // 0: G3, 1: G2, 2: G3 coarse, 3: G2 coarse
+    const bool g3 = (pass & 1) == 0;
+    const float cell = pass == 0 ? cell3_of(which) : pass == 1 ? kCell2 : pass == 2 ? cell3_of(which) * kCell3CoarseFactor : kCell2Coarse;
+    const float inv = 1.0f / cell;
+    int* start = pass == 0 ? g.start3 : pass == 1 ? g.start2 : pass == 2 ? g.start3c : g.start2c;
+    float4* sorted = pass == 0 ? g.sorted3 : pass == 1 ? g.sorted2 : pass == 2 ? g.sorted3c : g.sorted2c;
     __syncthreads();
     for (int h = tid; h < g.H; h += 1024) cnt[h] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
       const float4 p = pts[i];
       const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
-      const int iz = pass == 0 ? (int)floorf(p.z * inv) : (int)p.w;
+      const int iz = g3 ? (int)floorf(p.z * inv) : (int)p.w;
       atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
     }
     __syncthreads();
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
       const float4 p = pts[i];
       const int key = (int)p.w;
       const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
-      const int iz = pass == 0 ? (int)floorf(p.z * inv) : key;
+      const int iz = g3 ? (int)floorf(p.z * inv) : key;
       const int pos = atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
       sorted[pos] = make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)i | ((unsigned)(key + 1) << 20)));
     }
@@ -188,10 +194,26 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int whi
     if (v < best) best = v;
   };
   if (g.flags[0] == 0) {
-    const float cell = cell3_of(which), inv = 1.0f / cell;
-    const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv), cz = (int)floorf(sel.z * inv);
+    const float cell = cell3_of(which);
+    {  // level 0: the 3x3x3 block of fine cells
+      const float inv = 1.0f / cell;
+      const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv), cz = (int)floorf(sel.z * inv);
+      int s0 = 0, cnt = 0;
+      if (lane < 27) {
+        const unsigned h = hash3(cx + lane % 3 - 1, cy + (lane % 9) / 3 - 1, cz + lane / 9 - 1) & (unsigned)(g.H - 1);
+        s0 = g.start3[h];
+        cnt = g.start3[h + 1] - s0;
+      }
+      wave_sweep(g.sorted3, s0, cnt, lane, visit);
+      best = wave_min_u64(best);
+      const float bound = (1.0f - 0.01f) * cell;                       // every unvisited point is farther than `bound`
+      if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= bound * bound) return best;
+    }
+    // level 1: expanding cubic shells of coarse cells (at most three steps reach DISTANCE_SQ_THRESHOLD)
+    const float cellc = cell * kCell3CoarseFactor, invc = 1.0f / cellc;
+    const int ux = (int)floorf(sel.x * invc), uy = (int)floorf(sel.y * invc), uz = (int)floorf(sel.z * invc);
     for (int r = 1;; ++r) {
-      const int ncell = r == 1 ? 27 : 24 * r * r + 2;            // first step: the whole 3x3x3 cube
+      const int ncell = r == 1 ? 27 : 24 * r * r + 2;
       for (int cb = 0; cb < ncell; cb += 64) {
         const int c = cb + lane;
         int s0 = 0, cnt = 0;
@@ -199,16 +221,16 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int whi
           int dx, dy, dz;
           if (r == 1) { dz = c / 9 - 1; dy = (c % 9) / 3 - 1; dx = c % 3 - 1; }
           else shell3d(r, c, &dx, &dy, &dz);
-          const unsigned h = hash3(cx + dx, cy + dy, cz + dz) & (unsigned)(g.H - 1);
-          s0 = g.start3[h];
-          cnt = g.start3[h + 1] - s0;
+          const unsigned h = hash3(ux + dx, uy + dy, uz + dz) & (unsigned)(g.H - 1);
+          s0 = g.start3c[h];
+          cnt = g.start3c[h + 1] - s0;
         }
-        wave_sweep(g.sorted3, s0, cnt, lane, visit);
+        wave_sweep(g.sorted3c, s0, cnt, lane, visit);
       }
       best = wave_min_u64(best);
-      const float bound = ((float)r - 0.01f) * cell, b2 = bound * bound;   // every unvisited point is farther than `bound`
+      const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
       if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= b2) break;
-      if (b2 >= 25.0f) break;                                       // nothing within DISTANCE_SQ_THRESHOLD is left
+      if (b2 >= 25.0f) break;                                         // nothing within DISTANCE_SQ_THRESHOLD is left
     }
     return best;
   }
@@ -269,33 +291,31 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
     };
     if (g.flags[0] == 0 && jup > closest && jdown < closest) {
       // window form: candidates are exactly the indices (jdown, jup) \ {closest}; their keys lie in cid-2 .. cid+2
-      const float inv = 1.0f / kCell2;
-      const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv);
       auto visit = [&](const float4& p) {
         const unsigned wb = __float_as_uint(p.w);
         const int j = (int)(wb & kIdxMask), pk = (int)(wb >> 20) - 1;
         if (j > jdown && j < jup) consider(p, j, pk);
       };
-      for (int r = 1;; ++r) {
-        const int ncell = r == 1 ? 9 : 8 * r, nlook = ncell * 5;      // first step: the whole 3x3 block, 5 ring keys each
-        for (int cb = 0; cb < nlook; cb += 64) {
-          const int c = cb + lane;
-          int s0 = 0, cnt = 0;
-          if (c < nlook) {
-            const int key = cid + c % 5 - 2, cc = c / 5;
-            int dx, dy;
-            if (r == 1) { dy = cc / 3 - 1; dx = cc % 3 - 1; } else ring2d(r, cc, &dx, &dy);
-            if (key >= 0) {
-              const unsigned h = hash3(cx + dx, cy + dy, key) & (unsigned)(g.H - 1);
-              s0 = g.start2[h];
-              cnt = g.start2[h + 1] - s0;
-            }
+      // level 0: the 3x3 block of fine cells, 5 ring keys each (45 look-ups, one per lane); level 1, only if a neighbour may
+      // still be farther than the fine block reaches: the 3x3 block of coarse cells, which covers DISTANCE_SQ_THRESHOLD
+      for (int level = 0; level < 2; ++level) {
+        const float cell = level == 0 ? kCell2 : kCell2Coarse, inv = 1.0f / cell;
+        const int* st = level == 0 ? g.start2 : g.start2c;
+        const float4* so = level == 0 ? g.sorted2 : g.sorted2c;
+        const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv);
+        int s0 = 0, cnt = 0;
+        if (lane < 45) {
+          const int key = cid + lane % 5 - 2, cc = lane / 5;
+          if (key >= 0) {
+            const unsigned h = hash3(cx + cc % 3 - 1, cy + cc / 3 - 1, key) & (unsigned)(g.H - 1);
+            s0 = st[h];
+            cnt = st[h + 1] - s0;
           }
-          wave_sweep(g.sorted2, s0, cnt, lane, visit);
         }
+        wave_sweep(so, s0, cnt, lane, visit);
         best2 = wave_min_u64(best2);
         if (PLANE) best3 = wave_min_u64(best3);
-        const float bound = ((float)r - 0.01f) * kCell2, b2 = bound * bound;
+        const float bound = (1.0f - 0.01f) * cell, b2 = bound * bound;
         if (b2 >= 25.0f) break;
         const bool done2 = best2 != ~0ull && __uint_as_float((unsigned)(best2 >> 32)) <= b2;
         const bool done3 = !PLANE || (best3 != ~0ull && __uint_as_float((unsigned)(best3 >> 32)) <= b2);
