@@ -237,19 +237,25 @@ __global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// Neighbour suppression after a pick (reference src/scanRegistration.cpp:317-342 / :364-388).  flags bit0 = picked,
-// bit1 = "squared gap between point i and i+1 exceeds 0.05".  Executed by one wave; lanes 0..10 act.
-__device__ __forceinline__ void suppress_neighbours(volatile unsigned char* flags, int kf, int lane) {
-  bool g = false;
-  if (lane >= 1 && lane <= 5) g = (flags[kf + lane - 1] & 2) != 0;        // step (kf+l-1 -> kf+l), l = lane
-  else if (lane >= 6 && lane <= 10) g = (flags[kf - (lane - 5)] & 2) != 0; // step (kf-m -> kf-m+1), m = lane-5
-  const unsigned long long gb = __ballot(g);
-  const unsigned fwd = (unsigned)(gb >> 1) & 31u, bwd = (unsigned)(gb >> 6) & 31u;
-  const int nf = fwd ? (__ffs((int)fwd) - 1) : 5;      // number of forward neighbours marked
-  const int nb = bwd ? (__ffs((int)bwd) - 1) : 5;
-  if (lane == 0) flags[kf] = flags[kf] | 1;
-  else if (lane >= 1 && lane <= 5) { if (lane - 1 < nf) flags[kf + lane] = flags[kf + lane] | 1; }
-  else if (lane >= 6 && lane <= 10) { if (lane - 6 < nb) flags[kf - (lane - 5)] = flags[kf - (lane - 5)] | 1; }
+// Neighbour suppression after picking local point kf (reference src/scanRegistration.cpp:317-342 / :364-388): kf+1 .. kf+nf
+// and kf-1 .. kf-nb get marked, each run stopping at the first consecutive-point gap whose square exceeds 0.05.
+// flags bit0 = picked, bit1 = "squared gap between point i and i+1 exceeds 0.05".  One LDS read (lanes 0..10 fetch the bytes
+// kf-5 .. kf+5: gap bits for the ballot, and the byte each of them may have to update), no read-back: the caller applies the
+// same marks to the candidates it holds in registers.  NOTE: the LDS arrays are deliberately NOT volatile — volatile accesses
+// are not promoted from the generic to the LDS address space and turn into flat_load / flat_store + s_waitcnt vmcnt(0)
+// (several hundred cycles per pick).  One wave's LDS operations complete in program order and the compiler cannot reorder
+// may-alias accesses to the same array, which is all the single-wave picking loop needs.
+__device__ __forceinline__ void suppress_neighbours(unsigned char* flags, int kf, int lane, int* nf_out, int* nb_out) {
+  const int off = lane - 5;
+  unsigned char byte = 0;
+  if (lane <= 10) byte = flags[kf + off];
+  const unsigned gb = (unsigned)__ballot((byte & 2) != 0);
+  const unsigned fwd = (gb >> 5) & 31u, bwd = gb & 31u;              // steps kf.. kf+4 ; steps kf-5 .. kf-1
+  const int nf = fwd ? (__ffs((int)fwd) - 1) : 5;                     // first gap going forward
+  const int nb = bwd ? (__clz((int)bwd) - 27) : 5;                    // first gap going backward: 4 - (31 - clz) = clz - 27
+  if (lane <= 10 && (off == 0 || (off > 0 && off <= nf) || (off < 0 && -off <= nb))) flags[kf + off] = byte | 1;
+  *nf_out = nf;
+  *nb_out = nb;
 }
 
 template <int NPAD>
@@ -274,15 +280,15 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
   // all scratch lives in the dynamic region so its base stays 16-byte aligned (no static __shared__ in front)
   constexpr int FLAG_BYTES = (MAXN + 15) & ~15;
-  volatile unsigned char* flags = smem + ((A_BYTES + 15) & ~15);
-  volatile signed char* label = reinterpret_cast<volatile signed char*>(flags + FLAG_BYTES);
+  unsigned char* flags = smem + ((A_BYTES + 15) & ~15);
+  signed char* label = reinterpret_cast<signed char*>(flags + FLAG_BYTES);
   int* s_scan = reinterpret_cast<int*>(smem + ((A_BYTES + 15) & ~15) + 2 * FLAG_BYTES);
   float (*s_red)[4] = reinterpret_cast<float (*)[4]>(s_scan + 256);
   int* s_misc = reinterpret_cast<int*>(s_scan + 256 + 24);
   // picks of the 6 sectors (local indices), staged in LDS so that the serial picking loop issues no global store:
   // [j][0..1] sharp, [j][2..21] less sharp, [j][22..25] flat
   constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
-  volatile short* s_pick = reinterpret_cast<volatile short*>(s_misc + 8);
+  short* s_pick = reinterpret_cast<short*>(s_misc + 8);
 
   const float4* cloud = a.cloud + (long long)b * a.cap + start;
   for (int i = tid; i < n; i += 256) {
@@ -349,22 +355,22 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
         const unsigned long long key = valid ? keys[pos] : 0ull;
         const int kpt = (int)(key & 0xffffull);
         const float c = __uint_as_float((unsigned)((key >> 16) & 0xffffffffull));
-        bool cand = valid && ((double)c > 0.1);
+        bool cand = valid && ((double)c > 0.1) && !(flags[kpt] & 1);
         while (true) {
-          const bool ok = cand && !(flags[kpt] & 1);
-          const unsigned long long mask = __ballot(ok);
+          const unsigned long long mask = __ballot(cand);
           if (!mask) break;
           const int f = __ffsll((long long)mask) - 1;
-          const int kf = __shfl(kpt, f, 64);
+          const int kf = __builtin_amdgcn_readlane(kpt, f);                 // f is wave-uniform: no LDS shuffle between two picks
           ++count;
           if (count > kLessSharpPerSector) { done = true; break; }           // 21st: break before marking (:312-315)
           if (lane == 0) {
             label[kf] = count <= kSharpPerSector ? 2 : 1;
             s_pick[j * kSlots + kSharpPerSector + count - 1] = (short)kf;
           }
-          suppress_neighbours(flags, kf, lane);
-          __builtin_amdgcn_wave_barrier();     // single wave, volatile LDS: program order is enough, no memory fence
-          cand = cand && lane > f;
+          int nf, nb;
+          suppress_neighbours(flags, kf, lane, &nf, &nb);
+          const int d = kpt - kf;                                             // the same marks, applied to the candidates in registers
+          if (d == 0 || (d > 0 && d <= nf) || (d < 0 && -d <= nb)) cand = false;
         }
       }
       const int ncorner = count > kLessSharpPerSector ? kLessSharpPerSector : count;
@@ -377,19 +383,19 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
         const unsigned long long key = valid ? keys[pos] : 0ull;
         const int kpt = (int)(key & 0xffffull);
         const float c = __uint_as_float((unsigned)((key >> 16) & 0xffffffffull));
-        bool cand = valid && ((double)c < 0.1);
+        bool cand = valid && ((double)c < 0.1) && !(flags[kpt] & 1);
         while (true) {
-          const bool ok = cand && !(flags[kpt] & 1);
-          const unsigned long long mask = __ballot(ok);
+          const unsigned long long mask = __ballot(cand);
           if (!mask) break;
           const int f = __ffsll((long long)mask) - 1;
-          const int kf = __shfl(kpt, f, 64);
+          const int kf = __builtin_amdgcn_readlane(kpt, f);
           if (lane == 0) { label[kf] = -1; s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + count] = (short)kf; }
           ++count;
           if (count >= kFlatPerSector) { done = true; break; }                // 4th: break before marking (:359-362)
-          suppress_neighbours(flags, kf, lane);
-          __builtin_amdgcn_wave_barrier();
-          cand = cand && lane > f;
+          int nf, nb;
+          suppress_neighbours(flags, kf, lane, &nf, &nb);
+          const int d = kpt - kf;
+          if (d == 0 || (d > 0 && d <= nf) || (d < 0 && -d <= nb)) cand = false;
         }
       }
       if (lane == 0) {
