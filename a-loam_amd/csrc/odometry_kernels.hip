@@ -91,7 +91,10 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
     for (int k = 0; k < KT; ++k) { run = tab[KT + k] > run ? tab[KT + k] : run; g.last_le[k] = is_bad ? 0x7fffffff : run; }
     g.flags[0] = is_bad;
   }
-  if (is_bad) return;
+  if (is_bad || n == 0) {
+    if (n == 0) for (int pass = 0; pass < 4; ++pass) { int* st = pass == 0 ? g.start3 : pass == 1 ? g.start2 : pass == 2 ? g.start3c : g.start2c; for (int h = tid; h <= g.H; h += 1024) st[h] = 0; }
+    return;
+  }
   for (int pass = 0; pass < 4; ++pass) {          // 0: G3, 1: G2, 2: G3 coarse, 3: G2 coarse
     const bool g3 = (pass & 1) == 0;
     const float cell = pass == 0 ? cell3_of(which) : pass == 1 ? kCell2 : pass == 2 ? cell3_of(which) * kCell3CoarseFactor : kCell2Coarse;
@@ -101,11 +104,17 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
     __syncthreads();
     for (int h = tid; h < g.H; h += 1024) cnt[h] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-      const float4 p = pts[i];
-      const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
-      const int iz = g3 ? (int)floorf(p.z * inv) : (int)p.w;
-      atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
+    for (int base = 0; base < n; base += 4096) {            // four independent loads in flight per thread
+      float4 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; p[u] = pts[i < n ? i : n - 1]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (base + u * 1024 + tid >= n) continue;
+        const int ix = (int)floorf(p[u].x * inv), iy = (int)floorf(p[u].y * inv);
+        const int iz = g3 ? (int)floorf(p[u].z * inv) : (int)p[u].w;
+        atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
+      }
     }
     __syncthreads();
     // exclusive scan of cnt[H]: per-thread run of H/1024 consecutive buckets + scan of the 1024 partial sums
@@ -124,13 +133,20 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
     for (int k = 0; k < per; ++k) { const int c = cnt[tid * per + k]; cnt[tid * per + k] = run; start[tid * per + k] = run; run += c; }
     if (tid == 1023) start[g.H] = run;
     __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-      const float4 p = pts[i];
-      const int key = (int)p.w;
-      const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
-      const int iz = g3 ? (int)floorf(p.z * inv) : key;
-      const int pos = atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
-      sorted[pos] = make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)i | ((unsigned)(key + 1) << 20)));
+    for (int base = 0; base < n; base += 4096) {
+      float4 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; p[u] = pts[i < n ? i : n - 1]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = base + u * 1024 + tid;
+        if (i >= n) continue;
+        const int key = (int)p[u].w;
+        const int ix = (int)floorf(p[u].x * inv), iy = (int)floorf(p[u].y * inv);
+        const int iz = g3 ? (int)floorf(p[u].z * inv) : key;
+        const int pos = atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
+        sorted[pos] = make_float4(p[u].x, p[u].y, p[u].z, __uint_as_float((unsigned)i | ((unsigned)(key + 1) << 20)));
+      }
     }
   }
 }
