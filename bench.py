@@ -163,6 +163,19 @@ def main():
                 "algorithmic_bytes_per_launch": d["bytes_per_launch"],
                 "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in prof.items()}}
 
+    # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes of THIS command (tools/gpu_round.sh;
+    # MI355X_MICROARCH.md: counters in their own passes; FETCH_SIZE [KiB] reports half the bytes of wide coalesced reads on
+    # gfx950 -> doubled; WRITE_SIZE [KiB] as reported).  Only attached when the profiled configuration is this one.
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
+        if pm.get("batch") == B and pm.get("mapping") == bool(args.mapping) and pm.get("sensor") == args.sensor:
+            rk = {"k_associate[plane]": "k_associate<true>", "k_associate[corner]": "k_associate<false>", "k_ring_features": "k_ring_features<2048>"}.get(dname, dname)
+            if rk in pm["fetch_kib"] and rk in pm["write_kib"]:
+                roofline["traffic"] = round((2.0 * pm["fetch_kib"][rk] + pm["write_kib"][rk]) * 1024.0)
+                roofline["traffic_source"] = pm.get("source", "profiles/")
+    except (OSError, ValueError, KeyError):
+        pass
+
     out = {"metric": "HDL-64 scans/sec (whole node)", "value": round(value, 2), "unit": "scans/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",

@@ -19,4 +19,11 @@ python tools/rocprof_summary.py $O/stats/s_results.db $O/kernel_stats.md "rocpro
 python tools/pmc_summary.py /tmp/pmc_fetch $O/pmc_fetch.md > /dev/null
 python tools/pmc_summary.py /tmp/pmc_write $O/pmc_write.md > /dev/null
 rm -rf $O/stats
+python - <<PY
+import json
+f = json.load(open("$O/pmc_fetch.json")); w = json.load(open("$O/pmc_write.json"))
+json.dump({"batch": 256, "mapping": False, "sensor": "HDL-64", "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of python bench.py --no-cpu-baseline --steps 4 --warmup 1 (tools/gpu_round.sh $TAG)",
+           "fetch_kib": {k: v["FETCH_SIZE"] for k, v in f.items() if "FETCH_SIZE" in v}, "write_kib": {k: v["WRITE_SIZE"] for k, v in w.items() if "WRITE_SIZE" in v}},
+          open("$O/pmc_traffic.json", "w"), indent=1)
+PY
 cat $O/kernel_stats.md $O/pmc_fetch.md $O/pmc_write.md

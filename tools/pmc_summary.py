@@ -18,6 +18,9 @@ def main(d, out):
         kt["kernel"] = kt.Kernel_Name.str.extract(r"aloam::(\w+(?:<\w+>)?)")
         kt["us"] = (kt.End_Timestamp - kt.Start_Timestamp) / 1e3
         piv = piv.join(kt.groupby("kernel").us.mean().rename("avg_us"))
+    if out.endswith(".md"):   # machine-readable twin for bench.py's roofline.traffic
+        import json
+        json.dump({k: {c: float(v) for c, v in row.items() if v == v} for k, row in piv.to_dict(orient="index").items()}, open(out[:-3] + ".json", "w"), indent=1)
     with open(out, "w") as f:
         f.write("# rocprofv3 --pmc summary (mean per dispatch, aloam:: kernels only)\n\n```\n")
         f.write(piv.to_string(float_format=lambda v: f"{v:,.0f}"))
