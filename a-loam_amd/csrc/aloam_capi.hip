@@ -66,7 +66,7 @@ struct aloam_ctx {
   float4* d_stack[2] = {nullptr, nullptr}; float4* d_stack_world[2] = {nullptr, nullptr}; int* d_stack_cube[2] = {nullptr, nullptr};
   int *d_addcnt = nullptr, *d_cursor = nullptr;
   float4* d_mgrid_sorted[2] = {nullptr, nullptr}; int* d_mgrid_start[2] = {nullptr, nullptr}; int* d_mgrid_cnt[2] = {nullptr, nullptr};
-  MapEdgeRec* d_medges = nullptr; MapNormRec* d_mnorms = nullptr; float4* d_registered = nullptr;
+  MapEdgeRec* d_medges = nullptr; MapNormRec* d_mnorms = nullptr; float4* d_registered = nullptr; float4* d_knn = nullptr;
   VoxSeg* d_segs = nullptr; int *d_tile_seg = nullptr, *d_tile_heads = nullptr, *d_tile_pref = nullptr, *d_vox_counters = nullptr, *d_bbox = nullptr;
   unsigned long long* d_keys[2] = {nullptr, nullptr}; float4* d_voxtmp = nullptr;
   bool system_inited = false;        // reference src/laserOdometry.cpp:69
@@ -297,7 +297,7 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
                   c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
-                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp};
+                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -603,6 +603,10 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
         case K_ASSOC_CORNER: bytes += 16 * (Fc + Lcl) + 48 * Fc; break;
         case K_ASSOC_PLANE: bytes += 16 * (Fs + Lsl) + 64 * Fs; break;
         case K_SOLVE: bytes += 9.0 * (48 * Fc + 64 * Fs); break;
+        // mapping: incoming clouds read + stacks written; submap read + grid written; queries + 5 neighbours + records;
+        // 9 evaluations of the records; stacks -> cubes; valid cubes read + written; full cloud in + out
+        case K_MAP_VOXEL_STACK: bytes += 16 * (Lcl + Lsl) + 24 * (Lcl + Lsl); break;
+        case K_MAP_REGISTER: bytes += 32 * N; break;
         default: break;
       }
     }
@@ -627,7 +631,7 @@ static MapArgs map_args(aloam_ctx* c) {
     a.grid_sorted[k] = c->d_mgrid_sorted[k]; a.grid_start[k] = c->d_mgrid_start[k]; a.grid_cnt[k] = c->d_mgrid_cnt[k]; a.grid_H[k] = c->map_H[k];
   }
   a.addcnt = c->d_addcnt; a.cursor = c->d_cursor;
-  a.edges = c->d_medges; a.norms = c->d_mnorms;
+  a.edges = c->d_medges; a.norms = c->d_mnorms; a.knn = c->d_knn;
   a.lm_max_iterations = c->cfg.lm_max_iterations;
   return a;
 }
@@ -647,7 +651,7 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   c->map_line_res = line_res; c->map_plane_res = plane_res;
   c->map_pool = (pool_points + 1023) / 1024 * 1024;
   const size_t pool = c->map_pool;
-  for (int k = 0; k < 2; ++k) { int H = 4096; while (H < (int)pool / 2 && H < (1 << 20)) H <<= 1; c->map_H[k] = H; }
+  for (int k = 0; k < 2; ++k) { int H = 4096; while (H < (int)pool / 4 && H < (1 << 17)) H <<= 1; c->map_H[k] = H; }   // ~ submap size, not pool size
   const size_t max_seg = std::max(cap, pool);
   c->map_levels = 0;
   while (((size_t)kVoxTile << c->map_levels) < max_seg) ++c->map_levels;
@@ -677,6 +681,7 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   if ((rc = dmalloc(c, &c->d_medges, B * R * 120))) return rc;
   if ((rc = dmalloc(c, &c->d_mnorms, B * cap))) return rc;
   if ((rc = dmalloc(c, &c->d_registered, B * cap))) return rc;
+  if ((rc = dmalloc(c, &c->d_knn, B * cap * 4))) return rc;
   if ((rc = dmalloc(c, &c->d_segs, (size_t)c->map_nsegs_max))) return rc;
   if ((rc = dmalloc(c, &c->d_tile_seg, (size_t)c->map_tile_cap))) return rc;
   if ((rc = dmalloc(c, &c->d_tile_heads, (size_t)c->map_tile_cap))) return rc;

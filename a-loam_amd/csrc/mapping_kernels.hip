@@ -7,8 +7,8 @@
 //   k_vox_*            pcl::VoxelGrid::filter (:542-550 incoming clouds, :788-801 per-cube re-filter): bounding box ->
 //                      (voxel, index) 64-bit keys -> tile sort in LDS + rank-merge levels -> segment heads -> centroids in
 //                      input order; any number of independent segments per launch
-//   k_mapgrid_*        pcl::KdTreeFLANN::setInputCloud (:558-559): 1 m cell hash over the submap (global counting sort)
-//   k_map_associate    :576-706  pointAssociateToMap, nearestKSearch(k = 5) as an exact fixed-radius search (the reference
+//   k_mapgrid_*        pcl::KdTreeFLANN::setInputCloud (:558-559): 2 m cell hash over the submap (global counting sort)
+//   k_map_search/_fit  :576-706  pointAssociateToMap, nearestKSearch(k = 5) as an exact fixed-radius search (the reference
 //                      only uses the result when the 5th neighbour is closer than 1 m), line fit (3x3 symmetric
 //                      eigen-decomposition) / plane fit (5x3 least squares), factor records
 //   k_map_solve        :565-572,712-720 ceres::Solve over LidarEdgeFactor + LidarPlaneNormFactor blocks (shared LM loop,
@@ -52,6 +52,11 @@ __device__ __forceinline__ int cube_coord(double v, int cen) {
   if (v + 25.0 < 0) c--;
   return c;
 }
+
+// kd-tree stand-in of the submap: 2 m cells.  Every point closer than 1 m to a query lies in the 2x2x2 block of cells made of the
+// query's own cell and, per axis, the neighbour on the side of the cell the query sits in (8 bucket look-ups instead of the 27 a
+// 1 m grid needs).  Power-of-two cell size: p * 0.5f is exact, so cell membership is decided without rounding.
+constexpr float kMapCellInv = 0.5f;
 
 __device__ __forceinline__ CubeDesc* cube_table(const MapArgs& a, int b, int cls) { return a.cubes + ((long long)b * 2 + cls) * kMapCubes; }
 
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(1024) void k_vox_setup(VoxArgs v) {
 }
 
 __global__ __launch_bounds__(256) void k_vox_bbox(VoxArgs v) {
-  const int gt = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  if (gt >= v.counters[0]) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int gt = blockIdx.x; gt < v.counters[0]; gt += gridDim.x) {   // grid-stride over the tile work list
   const int s = v.tile_seg[gt];
   const VoxSeg sg = v.segs[s];
   const int t = gt - sg.tile0;
@@ -246,12 +251,13 @@ __global__ __launch_bounds__(256) void k_vox_bbox(VoxArgs v) {
     for (int d = 32; d > 0; d >>= 1) { mn[q] = fminf(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = fmaxf(mx[q], __shfl_down(mx[q], d, 64)); }
     if (lane == 0) { atomicMin(&v.bbox[s * 6 + q], f2o(mn[q])); atomicMax(&v.bbox[s * 6 + 3 + q], f2o(mx[q])); }
   }
+  }
 }
 
 // (voxel index, point index) keys of one tile, sorted in LDS.
 __global__ __launch_bounds__(256) void k_vox_keys_sort(VoxArgs v) {
-  const int gt = blockIdx.x, tid = threadIdx.x;
-  if (gt >= v.counters[0]) return;
+  const int tid = threadIdx.x;
+  for (int gt = blockIdx.x; gt < v.counters[0]; gt += gridDim.x) {   // grid-stride over the tile work list
   const int s = v.tile_seg[gt];
   const VoxSeg sg = v.segs[s];
   const int t = gt - sg.tile0;
@@ -290,37 +296,59 @@ __global__ __launch_bounds__(256) void k_vox_keys_sort(VoxArgs v) {
   bitonic_sort_u64(keys, kVoxTile, tid);
   unsigned long long* dst = v.keys[0] + sg.key_off;
   for (int e = tid; e < kVoxTile; e += 256) { const int i = t * kVoxTile + e; if (i < sg.n) dst[i] = keys[e]; }
+  __syncthreads();
+  }
 }
 
 // One rank-merge level: runs of `run` keys are merged pairwise; every key finds its place by a binary search in the sibling
 // run (keys are unique, so no tie rule is needed).  src = keys[level & 1], dst = the other buffer.
 __global__ __launch_bounds__(256) void k_vox_merge(VoxArgs v, int level) {
-  const int gt = blockIdx.x, tid = threadIdx.x;
-  if (gt >= v.counters[0]) return;
+  const int tid = threadIdx.x;
+  for (int gt = blockIdx.x; gt < v.counters[0]; gt += gridDim.x) {   // grid-stride over the tile work list
   const VoxSeg sg = v.segs[v.tile_seg[gt]];
   const int t = gt - sg.tile0;
   const unsigned long long* src = v.keys[level & 1] + sg.key_off;
   unsigned long long* dst = v.keys[(level & 1) ^ 1] + sg.key_off;
   const int run = kVoxTile << level;
-  for (int e = tid; e < kVoxTile; e += 256) {
-    const int p = t * kVoxTile + e;
-    if (p >= sg.n) break;
-    const unsigned long long key = src[p];
-    const int r = p / run, sib = r ^ 1;
-    const int sb = sib * run;
-    int dest = p;
-    if (sb < sg.n) {
-      int lo = sb, hi = min(sg.n, sb + run);                                // count of sibling keys < key
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (src[mid] < key) lo = mid + 1; else hi = mid; }
-      dest = (r >> 1) * 2 * run + (p - r * run) + (lo - sb);
+  constexpr int PER = kVoxTile / 256;
+  // all keys of a tile belong to the same run, so they search the same sibling range with the same number of steps: the
+  // PER searches of a thread are advanced in lock-step, PER independent loads in flight per step
+  const int p_first = t * kVoxTile;
+  const int r = p_first / run, sb = (r ^ 1) * run;
+  const bool has_sib = sb < sg.n;
+  const int s_end = has_sib ? min(sg.n, sb + run) : sb;
+  unsigned long long key[PER];
+  int lo[PER], hi[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int p = p_first + tid + u * 256;
+    key[u] = p < sg.n ? src[p] : ~0ull;
+    lo[u] = sb; hi[u] = s_end;
+  }
+  if (has_sib) {
+    for (int len = s_end - sb; len > 0; len >>= 1) {                    // ceil(log2(len + 1)) steps
+      unsigned long long probe[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) { const int mid = (lo[u] + hi[u]) >> 1; probe[u] = lo[u] < hi[u] ? src[mid] : 0ull; }
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        if (lo[u] < hi[u]) { const int mid = (lo[u] + hi[u]) >> 1; if (probe[u] < key[u]) lo[u] = mid + 1; else hi[u] = mid; }
+      }
     }
-    dst[dest] = key;
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int p = p_first + tid + u * 256;
+    if (p >= sg.n) continue;
+    const int dest = has_sib ? (r >> 1) * 2 * run + (p - r * run) + (lo[u] - sb) : p;
+    dst[dest] = key[u];
+  }
   }
 }
 
 __global__ __launch_bounds__(256) void k_vox_heads(VoxArgs v) {
-  const int gt = blockIdx.x, tid = threadIdx.x;
-  if (gt >= v.counters[0]) return;
+  const int tid = threadIdx.x;
+  for (int gt = blockIdx.x; gt < v.counters[0]; gt += gridDim.x) {   // grid-stride over the tile work list
   const VoxSeg sg = v.segs[v.tile_seg[gt]];
   const int t = gt - sg.tile0;
   const unsigned long long* K = v.keys[v.levels & 1] + sg.key_off;
@@ -336,6 +364,8 @@ __global__ __launch_bounds__(256) void k_vox_heads(VoxArgs v) {
   if ((tid & 63) == 0) atomicAdd(&s_sum, heads);
   __syncthreads();
   if (tid == 0) v.tile_heads[gt] = s_sum;
+  __syncthreads();
+  }
 }
 
 // exclusive prefix of the head counts over all tiles (one 1024-thread workgroup), per-segment output counts
@@ -377,8 +407,8 @@ __global__ __launch_bounds__(1024) void k_vox_scan(VoxArgs v) {
 
 // centroids: the head of every voxel run sums its members in key order (= input order) and writes output number `rank`
 __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs v) {
-  const int gt = blockIdx.x, tid = threadIdx.x;
-  if (gt >= v.counters[0]) return;
+  const int tid = threadIdx.x;
+  for (int gt = blockIdx.x; gt < v.counters[0]; gt += gridDim.x) {   // grid-stride over the tile work list
   const VoxSeg sg = v.segs[v.tile_seg[gt]];
   const int t = gt - sg.tile0;
   const unsigned long long* K = v.keys[v.levels & 1] + sg.key_off;
@@ -418,17 +448,20 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs v) {
     const float fc = (float)cnt;
     sg.out[rank++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
   }
+  __syncthreads();
+  }
 }
 
 // in-place re-filter of a map cube: copy the centroids from the scratch area back over the cube's segment
 __global__ __launch_bounds__(256) void k_vox_copyback(VoxArgs v) {
-  const int gt = blockIdx.x, tid = threadIdx.x;
-  if (gt >= v.counters[0]) return;
+  const int tid = threadIdx.x;
+  for (int gt = blockIdx.x; gt < v.counters[0]; gt += gridDim.x) {   // grid-stride over the tile work list
   const VoxSeg sg = v.segs[v.tile_seg[gt]];
-  if (!sg.final_out) return;
+  if (!sg.final_out) continue;
   const int t = gt - sg.tile0;
   const int m = v.tile_pref[min(sg.tile0 + sg.ntiles, v.counters[0])] - v.tile_pref[sg.tile0];
   for (int e = tid; e < kVoxTile; e += 256) { const int i = t * kVoxTile + e; if (i < m) sg.final_out[i] = sg.out[i]; }
+  }
 }
 
 // =======================================================================================================
@@ -438,18 +471,12 @@ __global__ __launch_bounds__(256) void k_mapgrid_count(MapArgs a) {
   const int b = blockIdx.y, cls = blockIdx.z;
   const MapSeq& ms = a.seq[b];
   const int n = ms.from_total[cls];
-  const int g0 = blockIdx.x * 1024;
-  if (g0 >= n) return;
   const int* tab = a.tab + (long long)b * kTabInts;
   const int H = a.grid_H[cls];
   int* cnt = a.grid_cnt[cls] + (long long)b * H;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int g = g0 + k * 256 + threadIdx.x;
-    if (g < n) {
-      const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
-      atomicAdd(&cnt[hash_cell((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (H - 1)], 1);
-    }
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
+    const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
+    atomicAdd(&cnt[hash_cell((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv)) & (H - 1)], 1);
   }
 }
 
@@ -479,20 +506,14 @@ __global__ __launch_bounds__(256) void k_mapgrid_fill(MapArgs a) {
   const int b = blockIdx.y, cls = blockIdx.z;
   const MapSeq& ms = a.seq[b];
   const int n = ms.from_total[cls];
-  const int g0 = blockIdx.x * 1024;
-  if (g0 >= n) return;
   const int* tab = a.tab + (long long)b * kTabInts;
   const int H = a.grid_H[cls];
   int* cur = a.grid_cnt[cls] + (long long)b * H;
   float4* sorted = a.grid_sorted[cls] + (long long)b * a.pool_cap;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int g = g0 + k * 256 + threadIdx.x;
-    if (g < n) {
-      const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
-      const int pos = atomicAdd(&cur[hash_cell((int)floorf(p.x), (int)floorf(p.y), (int)floorf(p.z)) & (H - 1)], 1);
-      sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(g));
-    }
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
+    const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
+    const int pos = atomicAdd(&cur[hash_cell((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv)) & (H - 1)], 1);
+    sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(g));
   }
 }
 
@@ -644,51 +665,96 @@ __device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[
 
 }  // namespace
 
+// Search half: lane per query, few registers, so that many waves hide the latency of the bucket walks.  Writes the five
+// neighbours (x, y, z each; ascending (distance, index)) or a "not found" mark to a.knn[query].
 template <int CLS>
-__global__ __launch_bounds__(256) void k_map_associate(MapArgs a, int iter) {
-  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-  MapSeq& ms = a.seq[b];
+__global__ __launch_bounds__(256) void k_map_search(MapArgs a) {
+  const int b = blockIdx.y;
+  const MapSeq& ms = a.seq[b];
   const int n = ms.n_stack[CLS];
-  if (i >= n) return;
   const long long sb = (long long)b * (CLS == 0 ? a.R * 120 : a.cap);
-  const float4 ori = a.stack[CLS][sb + i];                                 // pointOri (:578, :644)
-  bool valid = false;
-  double ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0}, rd = 0.0;
-  if (ms.gate) {
-    double par[7];
+  if (!ms.gate) return;
+  double par[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
-    const float4 sel = associate_to_map(ori, par);                         // pointSel (:580, :646)
-    const int H = a.grid_H[CLS];
-    const int* start = a.grid_start[CLS] + (long long)b * (H + 1);
-    const float4* sorted = a.grid_sorted[CLS] + (long long)b * a.pool_cap;
-    const int cx = (int)floorf(sel.x), cy = (int)floorf(sel.y), cz = (int)floorf(sel.z);
+  for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
+  const int H = a.grid_H[CLS];
+  const int* __restrict__ start = a.grid_start[CLS] + (long long)b * (H + 1);
+  const float4* __restrict__ sorted = a.grid_sorted[CLS] + (long long)b * a.pool_cap;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {   // grid-stride over the stack
+    const float4 sel = associate_to_map(a.stack[CLS][sb + i], par);        // pointSel (:580, :646)
+    const float gx = sel.x * kMapCellInv, gy = sel.y * kMapCellInv, gz = sel.z * kMapCellInv;
+    const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
+    const int nx = gx - (float)cx >= 0.5f ? cx + 1 : cx - 1, ny = gy - (float)cy >= 0.5f ? cy + 1 : cy - 1, nz = gz - (float)cz >= 0.5f ? cz + 1 : cz - 1;
     Top5 top;
     top.init();
-    // every point closer than 1 m lies in the 3x3x3 block of 1 m cells around the query; the reference discards the
-    // result unless the 5th neighbour is closer than 1 m (:582, :650), so this bounded search is an exact stand-in
-    for (int c = 0; c < 27; ++c) {
-      const int ex = cx + c % 3 - 1, ey = cy + (c / 3) % 3 - 1, ez = cz + c / 9 - 1;
-      const unsigned h = hash_cell(ex, ey, ez) & (unsigned)(H - 1);
-      const int s0 = start[h], s1 = start[h + 1];
-      for (int k = s0; k < s1; ++k) {
-        const float4 p = sorted[k];
-        if ((int)floorf(p.x) != ex || (int)floorf(p.y) != ey || (int)floorf(p.z) != ez) continue;   // another cell hashed into this bucket
+    // the reference discards the 5-NN result unless the 5th neighbour is closer than 1 m (:582, :650): collecting every point
+    // with d < 1 from the 2x2x2 block and keeping the five smallest (distance, index) is an exact stand-in
+    int s0[8], s1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                                            // the 8 bucket heads first: independent loads
+      const unsigned h = hash_cell((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz) & (unsigned)(H - 1);
+      s0[c] = start[h]; s1[c] = start[h + 1];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int ex = (c & 1) ? nx : cx, ey = (c & 2) ? ny : cy, ez = (c & 4) ? nz : cz;
+      auto visit = [&](const float4& p) {
+        if ((int)floorf(p.x * kMapCellInv) != ex || (int)floorf(p.y * kMapCellInv) != ey || (int)floorf(p.z * kMapCellInv) != ez) return;   // another cell hashed into this bucket
         const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
         const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;               // FLANN L2_Simple, f32
         if (d < 1.0f) top.insert(d, __float_as_int(p.w), p.x, p.y, p.z);
+      };
+      for (int k = s0[c]; k < s1[c]; k += 4) {                               // four independent loads in flight
+        const int m = s1[c] - k;
+        const float4 p0 = sorted[k], p1 = sorted[m > 1 ? k + 1 : k], p2 = sorted[m > 2 ? k + 2 : k], p3 = sorted[m > 3 ? k + 3 : k];
+        visit(p0);
+        if (m > 1) visit(p1);
+        if (m > 2) visit(p2);
+        if (m > 3) visit(p3);
       }
     }
-    if (top.d[4] < 1.0f) {                                                 // pointSearchSqDis[4] < 1.0
+    float4* out = a.knn + ((long long)b * a.cap + i) * 4;
+    const bool found = top.d[4] < 1.0f;                                      // pointSearchSqDis[4] < 1.0
+    out[0] = make_float4(top.x[0], top.y[0], top.z[0], found ? 1.f : 0.f);
+    out[1] = make_float4(top.x[1], top.y[1], top.z[1], top.x[2]);
+    out[2] = make_float4(top.y[2], top.z[2], top.x[3], top.y[3]);
+    out[3] = make_float4(top.z[3], top.x[4], top.y[4], top.z[4]);
+  }
+}
+
+// Fit half: line fit (corner) / plane fit (surf) in f64 on the five neighbours, validity tests, factor record.
+template <int CLS>
+__global__ __launch_bounds__(256) void k_map_fit(MapArgs a) {
+  const int b = blockIdx.y;
+  const MapSeq& ms = a.seq[b];
+  const int n = ms.n_stack[CLS];
+  const long long sb = (long long)b * (CLS == 0 ? a.R * 120 : a.cap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float4 ori = a.stack[CLS][sb + i];                               // pointOri (:578, :644)
+    bool valid = false;
+    double ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0}, rd = 0.0;
+    float nxs[5], nys[5], nzs[5];
+    bool found = false;
+    if (ms.gate) {
+      const float4* in = a.knn + ((long long)b * a.cap + i) * 4;
+      const float4 q0 = in[0], q1 = in[1], q2 = in[2], q3 = in[3];
+      found = q0.w != 0.f;
+      nxs[0] = q0.x; nys[0] = q0.y; nzs[0] = q0.z;
+      nxs[1] = q1.x; nys[1] = q1.y; nzs[1] = q1.z;
+      nxs[2] = q1.w; nys[2] = q2.x; nzs[2] = q2.y;
+      nxs[3] = q2.z; nys[3] = q2.w; nzs[3] = q3.x;
+      nxs[4] = q3.y; nys[4] = q3.z; nzs[4] = q3.w;
+    }
+    if (found) {
       if (CLS == 0) {
         double cxs = 0.0, cys = 0.0, czs = 0.0;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { cxs = cxs + (double)top.x[j]; cys = cys + (double)top.y[j]; czs = czs + (double)top.z[j]; }
+        for (int j = 0; j < 5; ++j) { cxs = cxs + (double)nxs[j]; cys = cys + (double)nys[j]; czs = czs + (double)nzs[j]; }
         const double ctr[3] = {cxs / 5.0, cys / 5.0, czs / 5.0};
         double cov[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-          const double zm[3] = {(double)top.x[j] - ctr[0], (double)top.y[j] - ctr[1], (double)top.z[j] - ctr[2]};
+          const double zm[3] = {(double)nxs[j] - ctr[0], (double)nys[j] - ctr[1], (double)nzs[j] - ctr[2]};
 #pragma unroll
           for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -704,7 +770,7 @@ __global__ __launch_bounds__(256) void k_map_associate(MapArgs a, int iter) {
       } else {
         double A[5][3], B[5] = {-1, -1, -1, -1, -1}, x[3];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) { A[j][0] = top.x[j]; A[j][1] = top.y[j]; A[j][2] = top.z[j]; }
+        for (int j = 0; j < 5; ++j) { A[j][0] = nxs[j]; A[j][1] = nys[j]; A[j][2] = nzs[j]; }
         lstsq_5x3(A, B, x);
         const double len = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
         const double d = 1 / len;                                          // negative_OA_dot_norm (:664)
@@ -712,27 +778,26 @@ __global__ __launch_bounds__(256) void k_map_associate(MapArgs a, int iter) {
         bool ok = true;
 #pragma unroll
         for (int j = 0; j < 5; ++j)
-          if (fabs(nx * (double)top.x[j] + ny * (double)top.y[j] + nz * (double)top.z[j] + d) > 0.2) ok = false;   // :672-678
+          if (fabs(nx * (double)nxs[j] + ny * (double)nys[j] + nz * (double)nzs[j] + d) > 0.2) ok = false;   // :672-678
         if (ok) { valid = true; ra[0] = nx; ra[1] = ny; ra[2] = nz; rd = d; }
       }
     }
-  }
-  if (CLS == 0) {
-    MapEdgeRec e;
-    e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
+    if (CLS == 0) {
+      MapEdgeRec e;
+      e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { e.a[k] = ra[k]; e.b[k] = rb[k]; }
-    e.valid = valid ? 1 : 0; e.pad = 0;
-    a.edges[(long long)b * a.R * 120 + i] = e;
-  } else {
-    MapNormRec e;
-    e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
+      for (int k = 0; k < 3; ++k) { e.a[k] = ra[k]; e.b[k] = rb[k]; }
+      e.valid = valid ? 1 : 0; e.pad = 0;
+      a.edges[(long long)b * a.R * 120 + i] = e;
+    } else {
+      MapNormRec e;
+      e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) e.n[k] = ra[k];
-    e.d = rd; e.valid = valid ? 1 : 0; e.pad = 0;
-    a.norms[(long long)b * a.cap + i] = e;
+      for (int k = 0; k < 3; ++k) e.n[k] = ra[k];
+      e.d = rd; e.valid = valid ? 1 : 0; e.pad = 0;
+      a.norms[(long long)b * a.cap + i] = e;
+    }
   }
-  (void)iter;
 }
 
 // =======================================================================================================
@@ -831,13 +896,13 @@ __global__ __launch_bounds__(256) void k_map_solve(MapArgs a, int iter, int last
 // map insertion (:737-783)
 // =======================================================================================================
 __global__ __launch_bounds__(256) void k_map_cubeid(MapArgs a) {
-  const int b = blockIdx.y, cls = blockIdx.z, i = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y, cls = blockIdx.z;
   const MapSeq& ms = a.seq[b];
-  if (i >= ms.n_stack[cls]) return;
   const long long sb = (long long)b * (cls == 0 ? a.R * 120 : a.cap);
   double par[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ms.n_stack[cls]; i += gridDim.x * 256) {
   const float4 w = associate_to_map(a.stack[cls][sb + i], par);
   const int ci = cube_coord((double)w.x, ms.cen[0]), cj = cube_coord((double)w.y, ms.cen[1]), ck = cube_coord((double)w.z, ms.cen[2]);
   int id = -1;
@@ -847,6 +912,7 @@ __global__ __launch_bounds__(256) void k_map_cubeid(MapArgs a) {
   }
   a.stack_world[cls][sb + i] = w;
   a.stack_cube[cls][sb + i] = id;
+  }
 }
 
 // capacity: a cube that would overflow its segment moves to a fresh one of twice the needed size (bump allocation from the
@@ -954,6 +1020,7 @@ void launch_map_cube_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s)
   hipLaunchKernelGGL(k_map_cube_segments, dim3((a.B * 2 * kMapValidMax + 255) / 256), dim3(256), 0, s, a, v);
 }
 void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
+  if (tile_bound > 8192) tile_bound = 8192;            // the kernels stride over the device-side tile list
   hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(1024), 0, s, v);
   hipLaunchKernelGGL(k_vox_bbox, dim3(tile_bound), dim3(256), 0, s, v);
   hipLaunchKernelGGL(k_vox_keys_sort, dim3(tile_bound), dim3(256), 0, s, v);
@@ -965,18 +1032,21 @@ void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
 }
 void launch_map_grid(const MapArgs& a, hipStream_t s) {
   for (int cls = 0; cls < 2; ++cls) (void)hipMemsetAsync(a.grid_cnt[cls], 0, sizeof(int) * (size_t)a.B * a.grid_H[cls], s);
-  const dim3 g((a.pool_cap + 1023) / 1024, a.B, 2);
+  const dim3 g(32, a.B, 2);                              // grid-stride over the submap of each (sequence, class)
   hipLaunchKernelGGL(k_mapgrid_count, g, dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_mapgrid_scan, dim3(a.B, 2), dim3(1024), 0, s, a);
   hipLaunchKernelGGL(k_mapgrid_fill, g, dim3(256), 0, s, a);
 }
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
-  hipLaunchKernelGGL(k_map_associate<0>, dim3((a.R * 120 + 255) / 256, a.B), dim3(256), 0, s, a, iter);
-  hipLaunchKernelGGL(k_map_associate<1>, dim3((a.cap + 255) / 256, a.B), dim3(256), 0, s, a, iter);
+  (void)iter;
+  hipLaunchKernelGGL(k_map_search<0>, dim3(16, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_fit<0>, dim3(16, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_search<1>, dim3(48, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) { hipLaunchKernelGGL(k_map_solve, dim3(a.B), dim3(256), 0, s, a, iter, last ? 1 : 0); }
 void launch_map_insert(const MapArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_map_cubeid, dim3((a.cap + 255) / 256, a.B, 2), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_cubeid, dim3(32, a.B, 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_map_reserve, dim3(a.B, 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_map_scatter, dim3(a.B, 2), dim3(64), 0, s, a);
 }

@@ -82,6 +82,7 @@ struct MapArgs {
   int* grid_start[2];            // [B][H + 1]
   int* grid_cnt[2];              // [B][H]
   int grid_H[2];
+  float4* knn;                   // [B][cap][4]  the five neighbours of every stack point (search -> fit)
   MapEdgeRec* edges;             // [B][R*120]
   MapNormRec* norms;             // [B][cap]
   int lm_max_iterations;
