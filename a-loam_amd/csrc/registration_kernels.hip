@@ -237,25 +237,106 @@ __global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// Neighbour suppression after picking local point kf (reference src/scanRegistration.cpp:317-342 / :364-388): kf+1 .. kf+nf
-// and kf-1 .. kf-nb get marked, each run stopping at the first consecutive-point gap whose square exceeds 0.05.
-// flags bit0 = picked, bit1 = "squared gap between point i and i+1 exceeds 0.05".  One LDS read (lanes 0..10 fetch the bytes
-// kf-5 .. kf+5: gap bits for the ballot, and the byte each of them may have to update), no read-back: the caller applies the
-// same marks to the candidates it holds in registers.  NOTE: the LDS arrays are deliberately NOT volatile — volatile accesses
-// are not promoted from the generic to the LDS address space and turn into flat_load / flat_store + s_waitcnt vmcnt(0)
-// (several hundred cycles per pick).  One wave's LDS operations complete in program order and the compiler cannot reorder
-// may-alias accesses to the same array, which is all the single-wave picking loop needs.
-__device__ __forceinline__ void suppress_neighbours(unsigned char* flags, int kf, int lane, int* nf_out, int* nb_out) {
-  const int off = lane - 5;
-  unsigned char byte = 0;
-  if (lane <= 10) byte = flags[kf + off];
-  const unsigned gb = (unsigned)__ballot((byte & 2) != 0);
-  const unsigned fwd = (gb >> 5) & 31u, bwd = gb & 31u;              // steps kf.. kf+4 ; steps kf-5 .. kf-1
-  const int nf = fwd ? (__ffs((int)fwd) - 1) : 5;                     // first gap going forward
-  const int nb = bwd ? (__clz((int)bwd) - 27) : 5;                    // first gap going backward: 4 - (31 - clz) = clz - 27
-  if (lane <= 10 && (off == 0 || (off > 0 && off <= nf) || (off < 0 && -off <= nb))) flags[kf + off] = byte | 1;
-  *nf_out = nf;
-  *nb_out = nb;
+// ---- wave-wide max / min of a 64-bit key without touching the LDS crossbar ---------------------------------------
+// value of lane ^ D inside a row of 16 lanes: D = 1, 2 one DPP quad permute; D = 4, 8 two DPP row shifts + a select.
+template <int D>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned v, int lane) {
+  if constexpr (D == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+  else {
+    const unsigned up = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x100 + D, 0xF, 0xF, true);            // row_shl:D  -> lane + D
+    const unsigned dn = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x110 + D, 0xF, 0xF, true);            // row_shr:D  -> lane - D
+    return (lane & D) ? dn : up;
+  }
+}
+template <int D, bool MAX>
+__device__ __forceinline__ unsigned long long row_step_u64(unsigned long long v, int lane) {
+  const unsigned lo = xor_lane_u32<D>((unsigned)v, lane), hi = xor_lane_u32<D>((unsigned)(v >> 32), lane);
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return MAX ? (o > v ? o : v) : (o < v ? o : v);
+}
+template <bool MAX>
+__device__ __forceinline__ unsigned long long wave_extreme_u64(unsigned long long v, int lane) {
+  v = row_step_u64<1, MAX>(v, lane);
+  v = row_step_u64<2, MAX>(v, lane);
+  v = row_step_u64<4, MAX>(v, lane);
+  v = row_step_u64<8, MAX>(v, lane);                                          // every lane holds the extreme of its row of 16
+  unsigned long long best = MAX ? 0ull : ~0ull;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * q), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * q);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    best = MAX ? (o > best ? o : best) : (o < best ? o : best);
+  }
+  return best;                                                                // wave-uniform
+}
+
+// Greedy corner / flat selection of ONE sector by ONE wave, with the whole sector in registers (reference
+// src/scanRegistration.cpp:284-390).  std::sort + "walk from the top, skip picked points" is evaluated as an iterative arg-max
+// over the still-unpicked points (arg-min for the flat points): same picks in the same order, no sort, no LDS traffic between
+// two picks.  A key is (curvature bits << 32 | local index << 8 | reach), reach = fw | bk << 3 = how far the neighbour
+// suppression of that point extends (:317-342, :364-388), so the winner carries everything a pick needs.
+//   init_marks : bit p set = point p (p < 5) of this sector was already marked by picks of the previous sector
+//   returns (through LDS) the picks, their counts and the marks this sector leaves on the first five points of the next one
+template <int K6>
+__device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, int lane, const float* curv_l, const unsigned char* flags,
+                                            short* s_pick, int* s_misc) {
+  constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
+  const int sp = (L * j) / 6, len = (L * (j + 1)) / 6 - sp;
+  const int last = sp + len - 1 + 5;                                          // local index of the sector's last point
+  unsigned long long key[K6];
+  unsigned alive = 0;
+#pragma unroll
+  for (int r = 0; r < K6; ++r) {
+    const int pos = r * 64 + lane;
+    key[r] = 0ull;
+    if (pos < len) {
+      const int i = sp + pos + 5;
+      key[r] = ((unsigned long long)__float_as_uint(curv_l[i]) << 32) | ((unsigned long long)i << 8) | (unsigned long long)(flags[i] >> 2);
+      if (!(pos < 5 && ((init_marks >> pos) & 1u))) alive |= 1u << r;
+    }
+  }
+  unsigned spill = 0;
+  auto mark = [&](unsigned long long best) {
+    const int kf = (int)((best >> 8) & 0x1fffull), fw = (int)(best & 7ull), bk = (int)((best >> 3) & 7ull);
+#pragma unroll
+    for (int r = 0; r < K6; ++r) {
+      const int d = (int)((key[r] >> 8) & 0x1fffull) - kf;
+      if (d == 0 || (d > 0 && d <= fw) || (d < 0 && -d <= bk)) alive &= ~(1u << r);
+    }
+    for (int off = 1; off <= fw; ++off) if (kf + off > last) spill |= 1u << (kf + off - last - 1);      // marks that land in the next sector
+    return kf;
+  };
+  // corners: largest curvature first (:291-344)
+  int count = 0;
+  while (true) {
+    unsigned long long loc = 0ull;
+#pragma unroll
+    for (int r = 0; r < K6; ++r) if (((alive >> r) & 1u) && key[r] > loc) loc = key[r];
+    const unsigned long long best = wave_extreme_u64<true>(loc, lane);
+    if (best == 0ull) break;
+    if (!((double)__uint_as_float((unsigned)(best >> 32)) > 0.1)) break;     // everything left is no corner candidate
+    ++count;
+    if (count > kLessSharpPerSector) break;                                   // 21st: break before marking (:312-315)
+    const int kf = mark(best);
+    if (lane == 0) s_pick[j * kSlots + kSharpPerSector + count - 1] = (short)kf;
+  }
+  const int ncorner = count > kLessSharpPerSector ? kLessSharpPerSector : count;
+  // flats: smallest curvature first (:346-390)
+  count = 0;
+  while (true) {
+    unsigned long long loc = ~0ull;
+#pragma unroll
+    for (int r = 0; r < K6; ++r) if (((alive >> r) & 1u) && key[r] < loc) loc = key[r];
+    const unsigned long long best = wave_extreme_u64<false>(loc, lane);
+    if (best == ~0ull) break;
+    if (!((double)__uint_as_float((unsigned)(best >> 32)) < 0.1)) break;
+    if (lane == 0) s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + count] = (short)((best >> 8) & 0x1fffull);
+    ++count;
+    if (count >= kFlatPerSector) break;                                       // 4th: break before marking (:359-362)
+    mark(best);
+  }
+  if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
 }
 
 template <int NPAD>
@@ -288,7 +369,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // picks of the 6 sectors (local indices), staged in LDS so that the serial picking loop issues no global store:
   // [j][0..1] sharp, [j][2..21] less sharp, [j][22..25] flat
   constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
-  short* s_pick = reinterpret_cast<short*>(s_misc + 8);
+  short* s_pick = reinterpret_cast<short*>(s_misc + 16);
 
   const float4* cloud = a.cloud + (long long)b * a.cap + start;
   for (int i = tid; i < n; i += 256) {
@@ -323,86 +404,68 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   }
   __syncthreads();
 
-  // ---- sort keys: (sector, curvature bits, local index); selectable points are local 5 .. n-7 (:249-251,284-285)
-  const int npad = pow2ceil(L);
+  // reach of the neighbour suppression around every point: a pick of i marks i+1 .. i+fw and i-1 .. i-bk (runs of consecutive
+  // gap-free steps, at most 5).  Packed into the flag byte: bit1 gap, bits 2-4 fw, bits 5-7 bk.
+  unsigned char rb[ITEMS];
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
     const int i = tid + it * 256;
-    const int e = i - 5;
-    if (e >= 0 && e < L) {
-      int sec = 5;
-      while (sec > 0 && (L * sec) / 6 > e) --sec;
-      keys[e] = ((unsigned long long)sec << 48) | ((unsigned long long)__float_as_uint(cv[it]) << 16) | (unsigned long long)i;
+    rb[it] = 0;
+    if (i < n) {
+      int fw = 0, bk = 0;
+      while (fw < 5 && i + fw < n - 1 && !(flags[i + fw] & 2)) ++fw;
+      while (bk < 5 && i - 1 - bk >= 0 && !(flags[i - 1 - bk] & 2)) ++bk;
+      rb[it] = (unsigned char)((fw << 2) | (bk << 5));
     }
   }
-  for (int e = L + tid; e < npad; e += 256) keys[e] = ~0ull;
+  __syncthreads();                                                           // tile and gap bits fully consumed
+  float* curv_l = reinterpret_cast<float*>(smem);                             // region A again: curvature per local point
+#pragma unroll
+  for (int it = 0; it < ITEMS; ++it) {
+    const int i = tid + it * 256;
+    if (i < n) { curv_l[i] = cv[it]; flags[i] = (unsigned char)(flags[i] | rb[it]); }
+  }
   __syncthreads();
-  bitonic_sort_u64(keys, npad, tid);
 
-  // ---- greedy picking, sectors in order (suppression marks spill across sector borders) — one wave
+  // ---- corner / flat selection (:284-390): every sector by its own wave, speculatively without the marks the previous
+  // sectors leave on its first five points; those marks only matter if the sector picked one of the marked points, which
+  // the second pass detects (and then redoes that sector with the marks) in sector order
+  constexpr int K6 = (NPAD / 6 + 2 + 63) / 64;
+  const int npad = pow2ceil(L);                                              // size of the voxel-key sort further down
+  for (int j = wave; j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);
+  __syncthreads();
+  if (wave == 0) {
+    unsigned carry = (unsigned)s_misc[8];                                    // marks on the (up to 5) points after sector 0
+    for (int j = 1; j < kSectors; ++j) {
+      const int sp = (L * j) / 6, len = (L * (j + 1)) / 6 - sp;
+      const unsigned m = len >= 5 ? carry : (carry & ((1u << len) - 1u));    // marks that fall inside this sector
+      if (m) {
+        const int nc = s_misc[1 + j] & 0xff, nfl = s_misc[1 + j] >> 8;
+        bool hit = false;
+        if (lane < kSlots) {
+          const int slot = lane;
+          const bool used = slot >= kSharpPerSector && (slot < kSharpPerSector + kLessSharpPerSector ? slot - kSharpPerSector < nc : slot - kSharpPerSector - kLessSharpPerSector < nfl);
+          if (used) { const int pos = s_pick[j * kSlots + slot] - 5 - sp; hit = pos < 5 && ((m >> pos) & 1u); }
+        }
+        if (__ballot(hit)) pick_sector<K6>(j, m, L, lane, curv_l, flags, s_pick, s_misc);
+      }
+      // a sector shorter than 5 points passes the rest of the incoming marks on to the sectors behind it
+      carry = (len >= 5 ? 0u : (carry >> len)) | (unsigned)s_misc[8 + j];
+    }
+  }
+  __syncthreads();
+  // labels of the picked points (cloudLabel: 2 sharp, 1 less sharp, -1 flat)
+  if (tid < kSectors * kSlots) {
+    const int j = tid / kSlots, slot = tid % kSlots;
+    const int nc = s_misc[1 + j] & 0xff, nfl = s_misc[1 + j] >> 8;
+    if (slot >= kSharpPerSector) {
+      if (slot < kSharpPerSector + kLessSharpPerSector) { const int q = slot - kSharpPerSector; if (q < nc) label[s_pick[j * kSlots + slot]] = q < kSharpPerSector ? 2 : 1; }
+      else { const int q = slot - kSharpPerSector - kLessSharpPerSector; if (q < nfl) label[s_pick[j * kSlots + slot]] = -1; }
+    }
+  }
   int* sharp_idx = a.sharp_idx + ((long long)(b * a.R + r) * kSectors) * kSharpPerSector;
   int* less_idx = a.less_sharp_idx + ((long long)(b * a.R + r) * kSectors) * kLessSharpPerSector;
   int* flat_idx = a.flat_idx + ((long long)(b * a.R + r) * kSectors) * kFlatPerSector;
-  if (wave == 0) {
-    for (int j = 0; j < kSectors; ++j) {
-      const int sp = (L * j) / 6, ep = (L * (j + 1)) / 6 - 1;
-      // corners: largest curvature first (:291-344)
-      int count = 0;
-      bool done = false;
-      for (int base = ep; base >= sp && !done; base -= 64) {
-        const int pos = base - lane;
-        const bool valid = pos >= sp;
-        const unsigned long long key = valid ? keys[pos] : 0ull;
-        const int kpt = (int)(key & 0xffffull);
-        const float c = __uint_as_float((unsigned)((key >> 16) & 0xffffffffull));
-        bool cand = valid && ((double)c > 0.1) && !(flags[kpt] & 1);
-        while (true) {
-          const unsigned long long mask = __ballot(cand);
-          if (!mask) break;
-          const int f = __ffsll((long long)mask) - 1;
-          const int kf = __builtin_amdgcn_readlane(kpt, f);                 // f is wave-uniform: no LDS shuffle between two picks
-          ++count;
-          if (count > kLessSharpPerSector) { done = true; break; }           // 21st: break before marking (:312-315)
-          if (lane == 0) {
-            label[kf] = count <= kSharpPerSector ? 2 : 1;
-            s_pick[j * kSlots + kSharpPerSector + count - 1] = (short)kf;
-          }
-          int nf, nb;
-          suppress_neighbours(flags, kf, lane, &nf, &nb);
-          const int d = kpt - kf;                                             // the same marks, applied to the candidates in registers
-          if (d == 0 || (d > 0 && d <= nf) || (d < 0 && -d <= nb)) cand = false;
-        }
-      }
-      const int ncorner = count > kLessSharpPerSector ? kLessSharpPerSector : count;
-      // flats: smallest curvature first (:346-390)
-      count = 0;
-      done = false;
-      for (int base = sp; base <= ep && !done; base += 64) {
-        const int pos = base + lane;
-        const bool valid = pos <= ep;
-        const unsigned long long key = valid ? keys[pos] : 0ull;
-        const int kpt = (int)(key & 0xffffull);
-        const float c = __uint_as_float((unsigned)((key >> 16) & 0xffffffffull));
-        bool cand = valid && ((double)c < 0.1) && !(flags[kpt] & 1);
-        while (true) {
-          const unsigned long long mask = __ballot(cand);
-          if (!mask) break;
-          const int f = __ffsll((long long)mask) - 1;
-          const int kf = __builtin_amdgcn_readlane(kpt, f);
-          if (lane == 0) { label[kf] = -1; s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + count] = (short)kf; }
-          ++count;
-          if (count >= kFlatPerSector) { done = true; break; }                // 4th: break before marking (:359-362)
-          int nf, nb;
-          suppress_neighbours(flags, kf, lane, &nf, &nb);
-          const int d = kpt - kf;
-          if (d == 0 || (d > 0 && d <= nf) || (d < 0 && -d <= nb)) cand = false;
-        }
-      }
-      if (lane == 0) {
-        s_misc[1 + j] = ncorner | (count << 8);
-      }
-    }
-  }
   __syncthreads();
   // picks out: sharp = the first two less-sharp picks (:301-311)
   if (tid < kSectors * kSlots) {
@@ -572,7 +635,7 @@ size_t ring_features_lds_bytes(int npad) {
   const int maxn = npad + 11;
   const int a_bytes = (12 * maxn > 8 * npad ? 12 * maxn : 8 * npad);
   const int flag_bytes = (maxn + 15) & ~15;
-  return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 8) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
+  return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 16) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
 }
 
 void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s) { hipLaunchKernelGGL(k_find_ends, dim3(a.B), dim3(1024), 0, s, a, d_nin); }
