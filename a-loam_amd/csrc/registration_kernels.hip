@@ -353,12 +353,11 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   if (n > MAXN) { if (tid == 0) atomicOr(&a.meta[b].err, kErrRingCap); return; }
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // region A: SoA xyz tile during the curvature pass, then the sort keys (aliased)
+  // region A: SoA xyz tile during the curvature pass, then the curvature per point, then voxel indices + run keys (aliased)
   constexpr int A_BYTES = (12 * MAXN > 8 * NPAD ? 12 * MAXN : 8 * NPAD);
   float* xs = reinterpret_cast<float*>(smem);
   float* ys = xs + MAXN;
   float* zs = ys + MAXN;
-  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
   // all scratch lives in the dynamic region so its base stays 16-byte aligned (no static __shared__ in front)
   constexpr int FLAG_BYTES = (MAXN + 15) & ~15;
   unsigned char* flags = smem + ((A_BYTES + 15) & ~15);
@@ -431,7 +430,6 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // sectors leave on its first five points; those marks only matter if the sector picked one of the marked points, which
   // the second pass detects (and then redoes that sector with the marks) in sector order
   constexpr int K6 = (NPAD / 6 + 2 + 63) / 64;
-  const int npad = pow2ceil(L);                                              // size of the voxel-key sort further down
   for (int j = wave; j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);
   __syncthreads();
   if (wave == 0) {
@@ -521,36 +519,64 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       fminb[q] = (float)minb[q];
     }
   }
-  for (int e = tid; e < npad; e += 256) {
-    unsigned long long key = ~0ull;
+  // Points follow the ring, so consecutive less-flat points mostly share a voxel: the sort works on RUNS of consecutive
+  // same-voxel members, keyed (voxel index, first element), typically a third of the points.  Runs of one voxel end up adjacent
+  // and in ascending element order, i.e. the members of a voxel are still summed in input order.
+  unsigned* vis = reinterpret_cast<unsigned*>(smem);                          // region A: voxel index per element [NPAD] ...
+  unsigned long long* rkeys = reinterpret_cast<unsigned long long*>(smem + 4 * NPAD);   // ... and the run keys [NPAD]
+  static_assert(4 * NPAD + 8 * NPAD <= A_BYTES, "region A holds the voxel indices and the run keys");
+  for (int e = tid; e < L; e += 256) {
     const int i = e + 5;
-    if (e < L && label[i] <= 0) {
-      const float4 p = cloud[i];
-      unsigned vi;
+    unsigned vi = 0xffffffffu;                                                // not a member (corner-labelled)
+    if (label[i] <= 0) {
       if (overflow) vi = (unsigned)e;         // every point its own cell -> output = input, in order
       else {
+        const float4 p = cloud[i];
         const int i0 = (int)(floorf(p.x * inv) - fminb[0]);
         const int i1 = (int)(floorf(p.y * inv) - fminb[1]);
         const int i2 = (int)(floorf(p.z * inv) - fminb[2]);
         vi = (unsigned)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]);
       }
-      key = ((unsigned long long)vi << 32) | (unsigned long long)i;
     }
-    keys[e] = key;
+    vis[e] = vi;
   }
   __syncthreads();
-  bitonic_sort_u64(keys, npad, tid);
-
-  // segment heads -> output rank (ascending voxel index), centroid = f32 sums in input order / count
-  const int chunk = npad / 256 > 0 ? npad / 256 : 1;
-  const int p0 = tid * chunk, p1 = (p0 + chunk < npad) ? p0 + chunk : npad;
-  int heads = 0;
-  for (int p = p0; p < p1 && p < npad; ++p) {
-    const unsigned long long key = keys[p];
-    if (key == ~0ull) break;
-    if (p == 0 || (unsigned)(keys[p - 1] >> 32) != (unsigned)(key >> 32)) ++heads;
+  // run heads: a member whose predecessor is no member or sits in another voxel (members have label <= 0, never 0xffffffff)
+  const int echunk = (L + 255) / 256;
+  const int e0 = tid * echunk, e1 = (e0 + echunk < L) ? e0 + echunk : L;
+  int nrun = 0;
+  for (int e = e0; e < e1; ++e) {
+    const unsigned vi = vis[e];
+    if (label[e + 5] <= 0 && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi)) ++nrun;
   }
-  if (tid * chunk >= npad) heads = 0;
+  s_scan[tid] = nrun;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int v = tid >= d ? s_scan[tid - d] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  const int n_runs = s_scan[255];
+  {
+    int rid = s_scan[tid] - nrun;
+    for (int e = e0; e < e1; ++e) {
+      const unsigned vi = vis[e];
+      if (label[e + 5] <= 0 && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi)) rkeys[rid++] = ((unsigned long long)vi << 32) | (unsigned long long)e;
+    }
+  }
+  const int rpad = pow2ceil(n_runs > 1 ? n_runs : 1);
+  for (int q = n_runs + tid; q < rpad; q += 256) rkeys[q] = ~0ull;
+  __syncthreads();
+  bitonic_sort_u64(rkeys, rpad, tid);
+
+  // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
+  const int chunk = (n_runs + 255) / 256;
+  const int p0 = tid * chunk, p1 = (p0 + chunk < n_runs) ? p0 + chunk : n_runs;
+  int heads = 0;
+  for (int p = p0; p < p1; ++p)
+    if (p == 0 || (unsigned)(rkeys[p - 1] >> 32) != (unsigned)(rkeys[p] >> 32)) ++heads;
+  __syncthreads();                                                           // s_scan is reused
   s_scan[tid] = heads;
   __syncthreads();
   for (int d = 1; d < 256; d <<= 1) {
@@ -562,19 +588,21 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   int rank = s_scan[tid] - heads;
   if (tid == 255) s_misc[0] = s_scan[255];
   float4* out = a.lf_ring + (long long)b * a.cap + start;
-  for (int p = p0; p < p1 && p < npad; ++p) {
-    const unsigned long long key = keys[p];
-    if (key == ~0ull) break;
-    const unsigned vi = (unsigned)(key >> 32);
-    if (p == 0 || (unsigned)(keys[p - 1] >> 32) != vi) {
+  for (int p = p0; p < p1; ++p) {
+    const unsigned vi = (unsigned)(rkeys[p] >> 32);
+    if (p == 0 || (unsigned)(rkeys[p - 1] >> 32) != vi) {
       float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
       int cnt = 0;
-      for (int q = p; q < npad; ++q) {
-        const unsigned long long kq = keys[q];
-        if ((unsigned)(kq >> 32) != vi || kq == ~0ull) break;
-        const float4 pt = cloud[(int)(kq & 0xffffffffull)];
-        sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
-        ++cnt;
+      for (int q = p; q < n_runs; ++q) {                                     // the runs of this voxel, in element order
+        const unsigned long long kq = rkeys[q];
+        if ((unsigned)(kq >> 32) != vi) break;
+        int e = (int)(unsigned)kq;
+        do {
+          const float4 pt = cloud[e + 5];
+          sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
+          ++cnt;
+          ++e;
+        } while (e < L && vis[e] == vi);                                      // a non-member carries 0xffffffff: the run stops there
       }
       const float fc = (float)cnt;
       out[rank++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
