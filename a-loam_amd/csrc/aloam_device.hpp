@@ -219,6 +219,40 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// ---- wave-wide max / min of a 64-bit key without touching the LDS crossbar ---------------------------------------
+// value of lane ^ D inside a row of 16 lanes: D = 1, 2 one DPP quad permute; D = 4, 8 two DPP row shifts + a select.
+template <int D>
+__device__ __forceinline__ unsigned xor_lane_u32(unsigned v, int lane) {
+  if constexpr (D == 1) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);          // quad_perm [1,0,3,2]
+  else if constexpr (D == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+  else {
+    const unsigned up = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x100 + D, 0xF, 0xF, true);            // row_shl:D  -> lane + D
+    const unsigned dn = (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x110 + D, 0xF, 0xF, true);            // row_shr:D  -> lane - D
+    return (lane & D) ? dn : up;
+  }
+}
+template <int D, bool MAX>
+__device__ __forceinline__ unsigned long long row_step_u64(unsigned long long v, int lane) {
+  const unsigned lo = xor_lane_u32<D>((unsigned)v, lane), hi = xor_lane_u32<D>((unsigned)(v >> 32), lane);
+  const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+  return MAX ? (o > v ? o : v) : (o < v ? o : v);
+}
+template <bool MAX>
+__device__ __forceinline__ unsigned long long wave_extreme_u64(unsigned long long v, int lane) {
+  v = row_step_u64<1, MAX>(v, lane);
+  v = row_step_u64<2, MAX>(v, lane);
+  v = row_step_u64<4, MAX>(v, lane);
+  v = row_step_u64<8, MAX>(v, lane);                                          // every lane holds the extreme of its row of 16
+  unsigned long long best = MAX ? 0ull : ~0ull;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * q), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * q);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    best = MAX ? (o > best ? o : best) : (o < best ? o : best);
+  }
+  return best;                                                                // wave-uniform
+}
+
 // LDS bitonic sort of npad (power of two) 64-bit keys, ascending, 256 threads.
 __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int npad, int tid) {
   for (int k = 2; k <= npad; k <<= 1) {

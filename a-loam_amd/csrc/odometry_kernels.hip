@@ -156,8 +156,7 @@ __device__ __forceinline__ float walk_dist(const float4& p, const float4& sel) {
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-  for (int msk = 32; msk > 0; msk >>= 1) { const unsigned long long o = shfl_xor_u64(v, msk); v = o < v ? o : v; }
-  return v;
+  return wave_extreme_u64<false>(v, (int)(threadIdx.x & 63));               // DPP row reduction + 4 readlanes, no LDS crossbar
 }
 
 // ---- shell enumeration -------------------------------------------------------------------------------------
