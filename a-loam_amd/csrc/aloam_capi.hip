@@ -5,7 +5,6 @@
 
 #include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -716,7 +715,6 @@ int aloam_mapping_step(aloam_ctx* c) {
     { ProfScope p(c, K_MAP_SOLVE); launch_map_solve(a, iter, iter == 1, c->stream); }
   }
   { ProfScope p(c, K_MAP_INSERT); launch_map_insert(a, c->stream); }        // :737-783
-  if (!getenv("ALOAM_DEBUG_SKIP_REFILTER"))
   { ProfScope p(c, K_MAP_VOXEL_CUBES);                                      // per-cube re-filter (:788-801)
     const VoxArgs v = vox_args(c, c->B * 2 * kMapValidMax);
     launch_map_cube_segments(a, v, c->stream);
