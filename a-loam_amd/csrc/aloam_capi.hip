@@ -650,7 +650,7 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   c->map_line_res = line_res; c->map_plane_res = plane_res;
   c->map_pool = (pool_points + 1023) / 1024 * 1024;
   const size_t pool = c->map_pool;
-  for (int k = 0; k < 2; ++k) { int H = 4096; while (H < (int)pool / 4 && H < (1 << 17)) H <<= 1; c->map_H[k] = H; }   // ~ submap size, not pool size
+  for (int k = 0; k < 2; ++k) { int H = 4096; while (H < (int)pool / 16 && H < (1 << 17)) H <<= 1; c->map_H[k] = H; }   // ~ submap size, not pool size
   const size_t max_seg = std::max(cap, pool);
   c->map_levels = 0;
   while (((size_t)kVoxTile << c->map_levels) < max_seg) ++c->map_levels;

@@ -36,8 +36,8 @@ __device__ __forceinline__ void add_row(double* acc, const double J[6], double r
   for (int i = 0; i < 6; ++i) acc[21 + i] += w * J[i] * r;
 }
 
-// block-wide sum of NV doubles per thread; result broadcast to every thread (s_red: [4][NV] doubles of LDS).
-template <int NV>
+// block-wide sum of NV doubles per thread over NW waves; result broadcast to every thread (s_red: [NW][NV] doubles of LDS).
+template <int NV, int NW = 4>
 __device__ __forceinline__ void block_sum(double* v, double* s_red) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -48,7 +48,10 @@ __device__ __forceinline__ void block_sum(double* v, double* s_red) {
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NV; ++k) v[k] = (s_red[k] + s_red[NV + k]) + (s_red[2 * NV + k] + s_red[3 * NV + k]);
+  for (int k = 0; k < NV; ++k) {
+    if (NW == 4) v[k] = (s_red[k] + s_red[NV + k]) + (s_red[2 * NV + k] + s_red[3 * NV + k]);
+    else { double x = s_red[k]; for (int w = 1; w < NW; ++w) x += s_red[w * NV + k]; v[k] = x; }
+  }
   __syncthreads();
 }
 
@@ -113,7 +116,7 @@ struct LmResult { int iterations, successful, termination, n_a, n_b; double init
 // scalar LM logic redundantly; only the evaluations are distributed.  `eval(with_jac, q, t, acc, &n_a, &n_b)` adds this
 // thread's share of the robustified sums at (q, t): acc[0..20] upper triangle of J^T J, acc[21..26] J^T r, acc[27] cost, and
 // counts the residual blocks of the two factor classes it visited.  q (xyzw) and t are updated in place.
-template <class Eval>
+template <int NW = 4, class Eval>
 __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], double t[3], int lm_max_iterations, double* s_red) {
   const double kFunctionTol = 1e-6, kGradientTol = 1e-10, kParameterTol = 1e-8, kMinRelDecrease = 1e-3;
   const double kMinDiag = 1e-6, kMaxDiag = 1e32, kMaxRadius = 1e16, kMinRadius = 1e-32;
@@ -123,8 +126,8 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
   int ne = 0, np = 0;
   eval(true, q, t, acc, &ne, &np);
   double cnt[2] = {(double)ne, (double)np};
-  block_sum<28>(acc, s_red);
-  block_sum<2>(cnt, s_red);
+  block_sum<28, NW>(acc, s_red);
+  block_sum<2, NW>(cnt, s_red);
   const int n_edges = (int)cnt[0], n_planes = (int)cnt[1];
 
   int iterations = 0, successful = 0, termination = 0;
@@ -186,7 +189,7 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
       for (int k = 0; k < 28; ++k) cacc[k] = 0.0;
       eval(false, qc, tc, cacc, &ne, &np);
       double cc[1] = {cacc[27]};
-      block_sum<1>(cc, s_red);
+      block_sum<1, NW>(cc, s_red);
       const double cost_c = cc[0];
       double sn = 0.0;
       for (int k = 0; k < 4; ++k) sn += (q[k] - qc[k]) * (q[k] - qc[k]);
@@ -201,7 +204,7 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
         x_norm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
         for (int k = 0; k < 28; ++k) acc[k] = 0.0;
         eval(true, q, t, acc, &ne, &np);
-        block_sum<28>(acc, s_red);
+        block_sum<28, NW>(acc, s_red);
         cost = acc[27];
         unpack(acc);
         gmax = gradient_max();

@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void k_vox_keys_sort(VoxArgs v) {
     keys[e] = key;
   }
   __syncthreads();
-  bitonic_sort_u64(keys, kVoxTile, tid);
+  const int in_tile = min(kVoxTile, sg.n - t * kVoxTile);                   // pads (all ones) beyond it are already in place
+  bitonic_sort_u64(keys, pow2ceil(in_tile), tid);
   unsigned long long* dst = v.keys[0] + sg.key_off;
   for (int e = tid; e < kVoxTile; e += 256) { const int i = t * kVoxTile + e; if (i < sg.n) dst[i] = keys[e]; }
   __syncthreads();
@@ -803,6 +804,7 @@ __global__ __launch_bounds__(256) void k_map_fit(MapArgs a) {
 // =======================================================================================================
 // solve
 // =======================================================================================================
+constexpr int kMapSolveThreads = 256;    // more waves do not pay: the kernel needs 256 VGPRs per lane for the f64 sums
 template <bool WITH_JAC>
 __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const double t[3], double* acc, int* n_edge, int* n_norm) {
   const int tid = threadIdx.x;
@@ -810,7 +812,7 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
   const MapEdgeRec* E = a.edges + (long long)b * a.R * 120;
   const MapNormRec* P = a.norms + (long long)b * a.cap;
   int ne = 0, np = 0;
-  for (int i = tid; i < ms.n_stack[0]; i += 256) {
+  for (int i = tid; i < ms.n_stack[0]; i += kMapSolveThreads) {
     const MapEdgeRec e = E[i];
     if (!e.valid) continue;
     ++ne;
@@ -841,7 +843,7 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
       }
     }
   }
-  for (int i = tid; i < ms.n_stack[1]; i += 256) {
+  for (int i = tid; i < ms.n_stack[1]; i += kMapSolveThreads) {
     const MapNormRec p = P[i];
     if (!p.valid) continue;
     ++np;
@@ -862,13 +864,13 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
   *n_norm = np;
 }
 
-__global__ __launch_bounds__(256) void k_map_solve(MapArgs a, int iter, int last) {
+__global__ __launch_bounds__(kMapSolveThreads) void k_map_solve(MapArgs a, int iter, int last) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  __shared__ double s_red[4 * 28];
+  __shared__ double s_red[(kMapSolveThreads / 64) * 28];
   MapSeq& ms = a.seq[b];
   double q[4] = {ms.par[0], ms.par[1], ms.par[2], ms.par[3]};
   double t[3] = {ms.par[4], ms.par[5], ms.par[6]};
-  const LmResult lm = lm_solve_block([&](bool with_jac, const double* qq, const double* tt, double* acc, int* ne, int* np) {
+  const LmResult lm = lm_solve_block<kMapSolveThreads / 64>([&](bool with_jac, const double* qq, const double* tt, double* acc, int* ne, int* np) {
     if (with_jac) map_evaluate<true>(a, b, qq, tt, acc, ne, np); else map_evaluate<false>(a, b, qq, tt, acc, ne, np);
   }, q, t, a.lm_max_iterations, s_red);
   if (tid == 0) {
@@ -1044,7 +1046,7 @@ void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
   hipLaunchKernelGGL(k_map_search<1>, dim3(48, a.B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
-void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) { hipLaunchKernelGGL(k_map_solve, dim3(a.B), dim3(256), 0, s, a, iter, last ? 1 : 0); }
+void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) { hipLaunchKernelGGL(k_map_solve, dim3(a.B), dim3(kMapSolveThreads), 0, s, a, iter, last ? 1 : 0); }
 void launch_map_insert(const MapArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_map_cubeid, dim3(32, a.B, 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_map_reserve, dim3(a.B, 2), dim3(256), 0, s, a);
