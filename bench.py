@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mapping", action="store_true", help="BASELINE configs[2]: also run the scan-to-map refinement every sweep")
     ap.add_argument("--map-pool", type=int, default=262144, help="device map capacity per sequence and class (points)")
+    ap.add_argument("--host-input", action="store_true", help="feed the sweeps from host memory through aloam_scan_register (PCIe-inclusive rate; "
+                    "reported as value_host_input next to the HBM-resident value, never instead of it)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,6 +152,24 @@ def main():
     prof = ctx.profile()
     ctx.profile_enable(False)
 
+    host_rate = None
+    if args.host_input:                                    # same steps, inputs handed over as host buffers (one H2D copy per sweep)
+        host = data.cpu().numpy()
+        hctx = binding.Aloam(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field, batch=B,
+                             max_points=NP, max_ring_points=2059 if model.columns <= 2048 else 4107, device=local_rank)
+        def hstep(k):
+            hctx.scan_register([host[b, k, : counts[b, k]] for b in range(B)], check=False)
+            hctx.odometry_step()
+        for k in order[: args.warmup]:
+            hstep(k)
+        hctx.synchronize()
+        th = time.perf_counter()
+        for k in order[args.warmup:]:
+            hstep(k)
+        hctx.synchronize()
+        host_rate = B * args.steps / (time.perf_counter() - th)
+        hctx.close()
+
     total_scans = world * B * args.steps
     value = total_scans / elapsed
 
@@ -182,6 +202,8 @@ def main():
            "config": {"workload": f"synthetic {args.sensor} {model.n_scans}x{model.columns} ({NP} pts/sweep), " + ("odometry + laserMapping scan-to-map refinement every sweep" if args.mapping else "odometry only (scan registration + scan-to-scan odometry, no laserMapping)"),
                       "sequences_per_gpu": B, "stored_frames": T, "points_per_sweep": NP, "parallelism": f"{world} x independent sequence shards, no collectives"},
            "roofline": roofline, "input_generation_s": round(t_gen, 2)}
+    if host_rate is not None:
+        out["value_host_input"] = round(host_rate, 2)      # per rank, PCIe-inclusive, pageable host buffers
 
     # ---- CPU baseline + accuracy (rank 0, N = 1 only) ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
