@@ -237,70 +237,105 @@ __global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
+// wave-wide max / min of a 32-bit value: DPP inside the rows of 16, v_readlane across the four rows (wave-uniform result)
+template <bool MAX>
+__device__ __forceinline__ unsigned wave_extreme_u32(unsigned v, int lane) {
+  unsigned o;
+  o = xor_lane_u32<1>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
+  o = xor_lane_u32<2>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
+  o = xor_lane_u32<4>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
+  o = xor_lane_u32<8>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
+  unsigned best = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+#pragma unroll
+  for (int q = 1; q < 4; ++q) { const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)v, 16 * q); best = MAX ? (x > best ? x : best) : (x < best ? x : best); }
+  return best;
+}
+
 // Greedy corner / flat selection of ONE sector by ONE wave, with the whole sector in registers (reference
 // src/scanRegistration.cpp:284-390).  std::sort + "walk from the top, skip picked points" is evaluated as an iterative arg-max
-// over the still-unpicked points (arg-min for the flat points): same picks in the same order, no sort, no LDS traffic between
-// two picks.  A key is (curvature bits << 32 | local index << 8 | reach), reach = fw | bk << 3 = how far the neighbour
-// suppression of that point extends (:317-342, :364-388), so the winner carries everything a pick needs.
-//   init_marks : bit p set = point p (p < 5) of this sector was already marked by picks of the previous sector
-//   returns (through LDS) the picks, their counts and the marks this sector leaves on the first five points of the next one
+// over the still-unpicked points (arg-min for the flat points): same picks in the same order — ties in curvature go to the
+// larger index for corners and to the smaller one for flats, exactly what an ascending sort by (curvature, index) gives — no
+// sort, no LDS traffic between two picks.  Point `pos` of the sector lives in register pos / 64 of lane pos % 64, so a pick
+// at (register kr, lane f) can only touch registers kr-1, kr, kr+1 and the marks become three lane-distance tests.
+//   init_marks : bit p set = point p (p < 5) of this sector was already marked by picks of the sectors before it
+//   returns (through LDS) the picks, their counts and the marks this sector leaves on the five points behind it
 template <int K6>
 __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, int lane, const float* curv_l, const unsigned char* flags,
                                             short* s_pick, int* s_misc) {
   constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
+  constexpr int NRP = (K6 + 4) / 5;                                           // reach bytes packed 5 x 6 bit per register
   const int sp = (L * j) / 6, len = (L * (j + 1)) / 6 - sp;
-  const int last = sp + len - 1 + 5;                                          // local index of the sector's last point
-  unsigned long long key[K6];
+  const int first = sp + 5, last = sp + len - 1 + 5;                          // local indices of the sector's first / last point
+  unsigned cb[K6];                                                            // curvature bits (non-negative floats order like integers)
+  unsigned rp[NRP];
   unsigned alive = 0;
+#pragma unroll
+  for (int q = 0; q < NRP; ++q) rp[q] = 0;
 #pragma unroll
   for (int r = 0; r < K6; ++r) {
     const int pos = r * 64 + lane;
-    key[r] = 0ull;
+    cb[r] = 0u;
     if (pos < len) {
-      const int i = sp + pos + 5;
-      key[r] = ((unsigned long long)__float_as_uint(curv_l[i]) << 32) | ((unsigned long long)i << 8) | (unsigned long long)(flags[i] >> 2);
+      const int i = first + pos;
+      cb[r] = __float_as_uint(curv_l[i]);
+      rp[r / 5] |= (unsigned)(flags[i] >> 2) << (6 * (r % 5));
       if (!(pos < 5 && ((init_marks >> pos) & 1u))) alive |= 1u << r;
     }
   }
   unsigned spill = 0;
-  auto mark = [&](unsigned long long best) {
-    const int kf = (int)((best >> 8) & 0x1fffull), fw = (int)(best & 7ull), bk = (int)((best >> 3) & 7ull);
+  // a pick at register kr of lane f: (fw, bk) = reach of the picked point; returns its local index
+  auto pick_at = [&](int kr, int f) {
+    unsigned rpk = 0;
 #pragma unroll
-    for (int r = 0; r < K6; ++r) {
-      const int d = (int)((key[r] >> 8) & 0x1fffull) - kf;
-      if (d == 0 || (d > 0 && d <= fw) || (d < 0 && -d <= bk)) alive &= ~(1u << r);
-    }
-    for (int off = 1; off <= fw; ++off) if (kf + off > last) spill |= 1u << (kf + off - last - 1);      // marks that land in the next sector
+    for (int q = 0; q < NRP; ++q) { const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)rp[q], f); if (q == kr / 5) rpk = x; }
+    const unsigned rb = (rpk >> (6 * (kr % 5))) & 63u;
+    const int fw = (int)(rb & 7u), bk = (int)(rb >> 3);
+    const int dl = lane - f;
+    unsigned kill = 0;
+    if (dl >= -bk && dl <= fw) kill |= 1u << kr;
+    if (dl + 64 >= 1 && dl + 64 <= fw) kill |= (1u << kr) << 1;
+    if (dl - 64 <= -1 && dl - 64 >= -bk) kill |= (1u << kr) >> 1;
+    alive &= ~kill;
+    const int kf = first + kr * 64 + f;
+    if (kf + fw > last) for (int off = 1; off <= fw; ++off) if (kf + off > last) spill |= 1u << (kf + off - last - 1);   // marks behind the sector
     return kf;
   };
   // corners: largest curvature first (:291-344)
   int count = 0;
   while (true) {
-    unsigned long long loc = 0ull;
+    unsigned bc = 0u;
+    int br = 0;
 #pragma unroll
-    for (int r = 0; r < K6; ++r) if (((alive >> r) & 1u) && key[r] > loc) loc = key[r];
-    const unsigned long long best = wave_extreme_u64<true>(loc, lane);
-    if (best == 0ull) break;
-    if (!((double)__uint_as_float((unsigned)(best >> 32)) > 0.1)) break;     // everything left is no corner candidate
+    for (int r = 0; r < K6; ++r) if (((alive >> r) & 1u) && cb[r] >= bc && cb[r] != 0u) { bc = cb[r]; br = r; }
+    const unsigned cmax = wave_extreme_u32<true>(bc, lane);
+    if (cmax == 0u || !((double)__uint_as_float(cmax) > 0.1)) break;         // nothing left that is a corner candidate
     ++count;
     if (count > kLessSharpPerSector) break;                                   // 21st: break before marking (:312-315)
-    const int kf = mark(best);
+    const unsigned long long tie = __ballot(bc == cmax);
+    int f, kr;
+    if (__popcll(tie) == 1) { f = __ffsll((long long)tie) - 1; kr = __builtin_amdgcn_readlane(br, f); }
+    else { const unsigned w = wave_extreme_u32<true>(bc == cmax ? (unsigned)(br * 64 + lane) : 0u, lane); f = (int)(w & 63u); kr = (int)(w >> 6); }
+    const int kf = pick_at(kr, f);
     if (lane == 0) s_pick[j * kSlots + kSharpPerSector + count - 1] = (short)kf;
   }
   const int ncorner = count > kLessSharpPerSector ? kLessSharpPerSector : count;
   // flats: smallest curvature first (:346-390)
   count = 0;
   while (true) {
-    unsigned long long loc = ~0ull;
+    unsigned bc = 0xffffffffu;
+    int br = 0;
 #pragma unroll
-    for (int r = 0; r < K6; ++r) if (((alive >> r) & 1u) && key[r] < loc) loc = key[r];
-    const unsigned long long best = wave_extreme_u64<false>(loc, lane);
-    if (best == ~0ull) break;
-    if (!((double)__uint_as_float((unsigned)(best >> 32)) < 0.1)) break;
-    if (lane == 0) s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + count] = (short)((best >> 8) & 0x1fffull);
+    for (int r = 0; r < K6; ++r) if (((alive >> r) & 1u) && cb[r] < bc) { bc = cb[r]; br = r; }
+    const unsigned cmin = wave_extreme_u32<false>(bc, lane);
+    if (cmin == 0xffffffffu || !((double)__uint_as_float(cmin) < 0.1)) break;
+    const unsigned long long tie = __ballot(bc == cmin);
+    int f, kr;
+    if (__popcll(tie) == 1) { f = __ffsll((long long)tie) - 1; kr = __builtin_amdgcn_readlane(br, f); }
+    else { const unsigned w = wave_extreme_u32<false>(bc == cmin ? (unsigned)(br * 64 + lane) : 0xffffffffu, lane); f = (int)(w & 63u); kr = (int)(w >> 6); }
+    if (lane == 0) s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + count] = (short)(first + kr * 64 + f);
     ++count;
     if (count >= kFlatPerSector) break;                                       // 4th: break before marking (:359-362)
-    mark(best);
+    pick_at(kr, f);
   }
   if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
 }
@@ -507,72 +542,93 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     vis[e] = vi;
   }
   __syncthreads();
-  // run heads: a member whose predecessor is no member or sits in another voxel (members have label <= 0, never 0xffffffff)
-  const int echunk = (L + 255) / 256;
-  const int e0 = tid * echunk, e1 = (e0 + echunk < L) ? e0 + echunk : L;
-  int nrun = 0;
-  for (int e = e0; e < e1; ++e) {
-    const unsigned vi = vis[e];
-    if (label[e + 5] <= 0 && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi)) ++nrun;
+  // run heads: a member whose predecessor is no member or sits in another voxel (members have label <= 0, never 0xffffffff).
+  // Elements are taken 256 at a time (element = it * 256 + tid: conflict-free LDS reads); the exclusive rank of a head in
+  // element order comes from wave ballots + a 4 x EIT table of wave counts — two barriers instead of a 16-barrier scan.
+  constexpr int EIT = NPAD / 256;
+  unsigned hmask = 0;                                                        // bit it: element it * 256 + tid starts a run
+  int hrank[EIT];
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int e = it * 256 + tid;
+    bool h = false;
+    if (e < L) { const unsigned vi = vis[e]; h = label[e + 5] <= 0 && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi); }
+    const unsigned long long m = __ballot(h);
+    hrank[it] = __popcll(m & ((1ull << lane) - 1ull));
+    if (h) hmask |= 1u << it;
+    if (lane == 0) s_scan[it * 4 + wave] = __popcll(m);
   }
-  s_scan[tid] = nrun;
   __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const int v = tid >= d ? s_scan[tid - d] : 0;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
-  }
-  const int n_runs = s_scan[255];
+  int n_runs = 0;
   {
-    int rid = s_scan[tid] - nrun;
-    for (int e = e0; e < e1; ++e) {
-      const unsigned vi = vis[e];
-      if (label[e + 5] <= 0 && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi)) rkeys[rid++] = ((unsigned long long)vi << 32) | (unsigned long long)e;
+    int run = 0;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int c = s_scan[it * 4 + w];
+        if (w == wave) hrank[it] += run;
+        run += c;
+      }
     }
+    n_runs = run;
   }
+#pragma unroll
+  for (int it = 0; it < EIT; ++it)
+    if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = ((unsigned long long)vis[e] << 32) | (unsigned long long)e; }
   const int rpad = pow2ceil(n_runs > 1 ? n_runs : 1);
   for (int q = n_runs + tid; q < rpad; q += 256) rkeys[q] = ~0ull;
   __syncthreads();
   bitonic_sort_u64(rkeys, rpad, tid);
 
   // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
-  const int chunk = (n_runs + 255) / 256;
-  const int p0 = tid * chunk, p1 = (p0 + chunk < n_runs) ? p0 + chunk : n_runs;
-  int heads = 0;
-  for (int p = p0; p < p1; ++p)
-    if (p == 0 || (unsigned)(rkeys[p - 1] >> 32) != (unsigned)(rkeys[p] >> 32)) ++heads;
+  unsigned vmask = 0;
+  int vrank[EIT];
   __syncthreads();                                                           // s_scan is reused
-  s_scan[tid] = heads;
-  __syncthreads();
-  for (int d = 1; d < 256; d <<= 1) {
-    const int v = tid >= d ? s_scan[tid - d] : 0;
-    __syncthreads();
-    s_scan[tid] += v;
-    __syncthreads();
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int p = it * 256 + tid;
+    const bool h = p < n_runs && (p == 0 || (unsigned)(rkeys[p - 1] >> 32) != (unsigned)(rkeys[p] >> 32));
+    const unsigned long long m = __ballot(h);
+    vrank[it] = __popcll(m & ((1ull << lane) - 1ull));
+    if (h) vmask |= 1u << it;
+    if (lane == 0) s_scan[it * 4 + wave] = __popcll(m);
   }
-  int rank = s_scan[tid] - heads;
-  if (tid == 255) s_misc[0] = s_scan[255];
-  float4* out = a.lf_ring + (long long)b * a.cap + start;
-  for (int p = p0; p < p1; ++p) {
-    const unsigned vi = (unsigned)(rkeys[p] >> 32);
-    if (p == 0 || (unsigned)(rkeys[p - 1] >> 32) != vi) {
-      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-      int cnt = 0;
-      for (int q = p; q < n_runs; ++q) {                                     // the runs of this voxel, in element order
-        const unsigned long long kq = rkeys[q];
-        if ((unsigned)(kq >> 32) != vi) break;
-        int e = (int)(unsigned)kq;
-        do {
-          const float4 pt = cloud[e + 5];
-          sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
-          ++cnt;
-          ++e;
-        } while (e < L && vis[e] == vi);                                      // a non-member carries 0xffffffff: the run stops there
+  __syncthreads();
+  {
+    int run = 0;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int c = s_scan[it * 4 + w];
+        if (w == wave) vrank[it] += run;
+        run += c;
       }
-      const float fc = (float)cnt;
-      out[rank++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
     }
+    if (tid == 0) s_misc[0] = run;                                           // number of occupied voxels = less-flat points of this ring
+  }
+  float4* out = a.lf_ring + (long long)b * a.cap + start;
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    if (!((vmask >> it) & 1u)) continue;
+    const int p = it * 256 + tid;
+    const unsigned vi = (unsigned)(rkeys[p] >> 32);
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    int cnt = 0;
+    for (int q = p; q < n_runs; ++q) {                                       // the runs of this voxel, in element order
+      const unsigned long long kq = rkeys[q];
+      if ((unsigned)(kq >> 32) != vi) break;
+      int e = (int)(unsigned)kq;
+      do {
+        const float4 pt = cloud[e + 5];
+        sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
+        ++cnt;
+        ++e;
+      } while (e < L && vis[e] == vi);                                        // a non-member carries 0xffffffff: the run stops there
+    }
+    const float fc = (float)cnt;
+    out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
   }
   __syncthreads();
   if (tid == 0) a.lf_cnt[b * a.R + r] = s_misc[0];
