@@ -136,3 +136,59 @@ def test_full_pipeline_registration_odometry_mapping(O, binding, sequence, name,
     gt = R[0].T @ (t[frames - 1] - t[0])
     assert np.linalg.norm(mg["t_w"] - gt) <= np.linalg.norm(pg["t_w"] - gt) + 0.05
     gpu.close()
+
+
+def test_full_size_mapping_batch(O, binding, syn):
+    """BASELINE configs[2] size: HDL-64, 131072 points per sweep, registration -> odometry -> mapping for a batch through the
+    device-resident entry point.  Sequence 0 against the oracle; size-independent properties for every sequence: the submap seen
+    by frame k is the map left by frame k-1, every down-sampled stack point lands in exactly one cube before the re-filter
+    (point-count conservation), the refined trajectory stays within a few centimetres of the synthetic ground truth."""
+    import torch
+    B, T = 3, 4
+    dev = torch.device("cuda", 0)
+    model = syn.sensor_model("HDL-64", device=dev)
+    NP = model.dirs.shape[0]
+    data = torch.zeros((B, T, NP, 4), dtype=torch.float32, device=dev)
+    counts = np.zeros((B, T), np.int32)
+    world = syn.make_world(555).to(dev)
+    gts = []
+    for b in range(B):
+        R, t = syn.trajectory(T, seed=70 + b, start_angle=0.4 * b)
+        gts.append((R.numpy(), t.numpy()))
+        gen = torch.Generator(device=dev).manual_seed(70 + b)
+        for k in range(T):
+            s = syn.render_scan(world, model, R[k], t[k], 0.02, gen)
+            counts[b, k] = len(s); data[b, k, :len(s)] = s
+    torch.cuda.synchronize()
+    gpu = binding.Aloam(n_scans=64, min_range=model.min_range, batch=B, max_points=NP, max_ring_points=2059)
+    gpu.mapping_enable(0.4, 0.8, pool_points=262144)
+    orc = O.Oracle(n_scans=64, min_range=model.min_range)
+    orc.map_config(0.4, 0.8)
+    host0 = data[0].cpu().numpy()
+    prev_total = [0] * B
+    for k in range(T):
+        gpu.process_device(data.data_ptr() + k * NP * 16, T * NP * 16, counts[:, k])
+        gpu.mapping_step()
+        gpu.synchronize()
+        orc.scan_register(host0[k, :counts[0, k]])
+        po = orc.odometry_step()
+        pm = orc.mapping_step(po["q_w"], po["t_w"], orc.cloud(O.CLOUD_CORNER_LAST), orc.cloud(O.CLOUD_SURF_LAST), orc.cloud(O.CLOUD_FULL))
+        mg = gpu.map_pose(0)
+        for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+            assert np.abs(pm[key] - mg[key]).max() < 1e-8, (k, key)
+        for cls in (0, 1):
+            _compare_maps(gpu.map_cubes(cls, 0), orc.map_cubes(cls), (k, cls), exact=False)
+        for b in range(B):
+            info = gpu.map_info(b)
+            total = sum(len(v) for v in gpu.map_cubes(0, b).values()) + sum(len(v) for v in gpu.map_cubes(1, b).values())
+            assert info["from_map_corner"] + info["from_map_surf"] == prev_total[b], (k, b, info, prev_total[b])   # the window holds the whole map here
+            assert prev_total[b] < total <= prev_total[b] + info["corner_stack"] + info["surf_stack"]
+            assert info["corner_stack"] > 1000 and info["surf_stack"] > 5000 and info["frame_count"] == k + 1
+            if k > 0:
+                assert info["corner_num1"] > 500 and info["surf_num1"] > 2000
+            prev_total[b] = total
+    for b in range(B):
+        Rg, tg = gts[b]
+        gt = Rg[0].T @ (tg[T - 1] - tg[0])
+        assert np.linalg.norm(gpu.map_pose(b)["t_w"] - gt) < 0.06, (b, gpu.map_pose(b)["t_w"], gt)
+    gpu.close()
