@@ -70,6 +70,13 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc) first; there is no CPU fallback")
+        # PyTorch-ROCm wheels bundle their own libamdhip64; if this process loads the system HIP runtime first (through
+        # libaloam_mi355x.so) and torch afterwards, torch's copy finds no device.  Loading torch first makes both use one runtime.
+        # The C library itself has no torch dependency; this only concerns Python processes that use both.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         vp, ip = C.c_void_p, C.POINTER(C.c_int)
         L.aloam_default_config.argtypes = [C.POINTER(AloamConfig)]; L.aloam_default_config.restype = None

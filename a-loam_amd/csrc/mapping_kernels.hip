@@ -308,6 +308,11 @@ __global__ __launch_bounds__(256) void k_vox_merge(VoxArgs v, int level) {
   for (int gt = blockIdx.x; gt < v.counters[0]; gt += gridDim.x) {   // grid-stride over the tile work list
   const VoxSeg sg = v.segs[v.tile_seg[gt]];
   const int t = gt - sg.tile0;
+  // a segment of ntiles tiles is sorted after ceil(log2(ntiles)) levels; after that it only has to end up in the buffer the
+  // later stages read (keys[levels & 1]): at most one copy, then nothing
+  int need = 0;
+  while ((1 << need) < sg.ntiles) ++need;
+  if (level > need || (level == need && ((v.levels - need) & 1) == 0)) continue;
   const unsigned long long* src = v.keys[level & 1] + sg.key_off;
   unsigned long long* dst = v.keys[(level & 1) ^ 1] + sg.key_off;
   const int run = kVoxTile << level;
@@ -415,13 +420,22 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs v) {
   const unsigned long long* K = v.keys[v.levels & 1] + sg.key_off;
   constexpr int PER = kVoxTile / 256;
   __shared__ int s_scan[256];
-  const int p0 = t * kVoxTile + tid * PER;
+  __shared__ float4 s_pts[kVoxTile];                                         // the tile's points in key order
+  __shared__ unsigned s_vi[kVoxTile];                                         // and their voxel indices
+  // stage the tile: every thread fetches its own members (independent loads); the serial per-voxel sums then run out of LDS
+  for (int e = tid; e < kVoxTile; e += 256) {
+    const int p = t * kVoxTile + e;
+    if (p < sg.n) { const unsigned long long k = K[p]; s_vi[e] = (unsigned)(k >> 32); s_pts[e] = sg.in[(unsigned)k]; }
+  }
+  __syncthreads();
+  const int e0 = tid * PER, p0 = t * kVoxTile + e0;
+  const int in_tile = min(kVoxTile, sg.n - t * kVoxTile);
   int heads = 0;
   unsigned flags = 0;
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
-    const int p = p0 + e;
-    if (p < sg.n && (p == 0 || (unsigned)(K[p - 1] >> 32) != (unsigned)(K[p] >> 32))) { ++heads; flags |= 1u << e; }
+    const int q = e0 + e;
+    if (q < in_tile && (q == 0 ? (p0 + e == 0 || (unsigned)(K[p0 + e - 1] >> 32) != s_vi[q]) : s_vi[q - 1] != s_vi[q])) { ++heads; flags |= 1u << e; }
   }
   s_scan[tid] = heads;
   __syncthreads();
@@ -435,16 +449,20 @@ __global__ __launch_bounds__(256) void k_vox_emit(VoxArgs v) {
 #pragma unroll 1
   for (int e = 0; e < PER; ++e) {
     if (!(flags & (1u << e))) continue;
-    const int p = p0 + e;
-    const unsigned vi = (unsigned)(K[p] >> 32);
+    const int q0 = e0 + e;
+    const unsigned vi = s_vi[q0];
     float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
     int cnt = 0;
-    for (int q = p; q < sg.n; ++q) {
-      const unsigned long long kq = K[q];
-      if ((unsigned)(kq >> 32) != vi) break;
-      const float4 pt = sg.in[(unsigned)kq];
-      sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
-      ++cnt;
+    int q = q0;
+    for (; q < in_tile && s_vi[q] == vi; ++q) { const float4 pt = s_pts[q]; sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w; ++cnt; }
+    if (q == in_tile) {                                                       // the voxel continues in the next tile(s): finish from global memory
+      for (int p = t * kVoxTile + q; p < sg.n; ++p) {
+        const unsigned long long kq = K[p];
+        if ((unsigned)(kq >> 32) != vi) break;
+        const float4 pt = sg.in[(unsigned)kq];
+        sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
+        ++cnt;
+      }
     }
     const float fc = (float)cnt;
     sg.out[rank++] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
@@ -904,16 +922,23 @@ __global__ __launch_bounds__(256) void k_map_cubeid(MapArgs a) {
   double par[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < ms.n_stack[cls]; i += gridDim.x * 256) {
-  const float4 w = associate_to_map(a.stack[cls][sb + i], par);
+  for (int i0 = blockIdx.x * 256; i0 < ms.n_stack[cls]; i0 += gridDim.x * 256) {
+  const int i = i0 + threadIdx.x;
+  const bool live = i < ms.n_stack[cls];
+  const float4 w = associate_to_map(a.stack[cls][sb + (live ? i : 0)], par);
   const int ci = cube_coord((double)w.x, ms.cen[0]), cj = cube_coord((double)w.y, ms.cen[1]), ck = cube_coord((double)w.z, ms.cen[2]);
   int id = -1;
-  if (ci >= 0 && ci < kMapW && cj >= 0 && cj < kMapH && ck >= 0 && ck < kMapD) {
-    id = ci + kMapW * cj + kMapW * kMapH * ck;
-    atomicAdd(&a.addcnt[((long long)b * 2 + cls) * kMapCubes + id], 1);
+  if (live && ci >= 0 && ci < kMapW && cj >= 0 && cj < kMapH && ck >= 0 && ck < kMapD) id = ci + kMapW * cj + kMapW * kMapH * ck;
+  // the points of one sweep fall into a dozen cubes: one atomic per distinct cube in the wave instead of one per point
+  unsigned long long todo = __ballot(id >= 0);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int c = __shfl(id, leader, 64);
+    const unsigned long long same = __ballot(id == c);
+    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&a.addcnt[((long long)b * 2 + cls) * kMapCubes + c], __popcll(same));
+    todo &= ~same;
   }
-  a.stack_world[cls][sb + i] = w;
-  a.stack_cube[cls][sb + i] = id;
+  if (live) { a.stack_world[cls][sb + i] = w; a.stack_cube[cls][sb + i] = id; }
   }
 }
 
