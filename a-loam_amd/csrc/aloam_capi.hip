@@ -59,7 +59,7 @@ struct aloam_ctx {
   // scan-to-map refinement (allocated by aloam_mapping_enable)
   bool map_on = false;
   float map_line_res = 0.4f, map_plane_res = 0.8f;
-  int map_pool = 0, map_H[2] = {0, 0}, map_levels = 0, map_tile_cap = 0, map_tile_bound[2] = {0, 0}, map_nsegs_max = 0;
+  int map_pool = 0, map_H[2] = {0, 0}, map_levels = 0, map_cube_levels = 0, map_tile_cap = 0, map_tile_bound[2] = {0, 0}, map_nsegs_max = 0;
   long long map_key_cap = 0;
   MapSeq* d_mapseq = nullptr; CubeDesc* d_cubes = nullptr; float4* d_pool[2] = {nullptr, nullptr}; int* d_maptab = nullptr;
   float4* d_stack[2] = {nullptr, nullptr}; float4* d_stack_world[2] = {nullptr, nullptr}; int* d_stack_cube[2] = {nullptr, nullptr};
@@ -320,7 +320,7 @@ int aloam_synchronize(aloam_ctx* c) {
     int vc[2] = {0, 0};
     HIP_TRY(c, hipMemcpy(ms.data(), c->d_mapseq, sizeof(MapSeq) * c->B, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(vc, c->d_vox_counters, sizeof(vc), hipMemcpyDeviceToHost));
-    if (vc[1]) { c->err = "mapping: voxel-filter scratch too small for the map (raise pool_points) or a cube holds more than 2^" + std::to_string(11 + c->map_levels) + " points"; return ALOAM_E_CAPACITY; }
+    if (vc[1]) { c->err = "mapping: voxel-filter scratch too small for the map (raise pool_points) or a cube holds more than 2^" + std::to_string(11 + c->map_cube_levels) + " points"; return ALOAM_E_CAPACITY; }
     for (int b = 0; b < c->B; ++b) if (ms[b].err & kMapErrPool) { c->err = "sequence " + std::to_string(b) + ": map pool exhausted (raise pool_points)"; return ALOAM_E_CAPACITY; }
   }
   return ALOAM_OK;
@@ -634,11 +634,11 @@ static MapArgs map_args(aloam_ctx* c) {
   a.lm_max_iterations = c->cfg.lm_max_iterations;
   return a;
 }
-static VoxArgs vox_args(aloam_ctx* c, int n_segs) {
+static VoxArgs vox_args(aloam_ctx* c, int n_segs, int levels) {
   VoxArgs v{};
   v.segs = c->d_segs; v.n_segs = n_segs; v.tile_seg = c->d_tile_seg; v.tile_heads = c->d_tile_heads; v.tile_pref = c->d_tile_pref;
   v.counters = c->d_vox_counters; v.keys[0] = c->d_keys[0]; v.keys[1] = c->d_keys[1]; v.tmp = c->d_voxtmp; v.bbox = c->d_bbox;
-  v.tile_cap = c->map_tile_cap; v.key_cap = c->map_key_cap; v.levels = c->map_levels;
+  v.tile_cap = c->map_tile_cap; v.key_cap = c->map_key_cap; v.levels = levels;
   return v;
 }
 
@@ -651,9 +651,10 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   c->map_pool = (pool_points + 1023) / 1024 * 1024;
   const size_t pool = c->map_pool;
   for (int k = 0; k < 2; ++k) { int H = 4096; while (H < (int)pool / 16 && H < (1 << 17)) H <<= 1; c->map_H[k] = H; }   // ~ submap size, not pool size
-  const size_t max_seg = std::max(cap, pool);
-  c->map_levels = 0;
-  while (((size_t)kVoxTile << c->map_levels) < max_seg) ++c->map_levels;
+  c->map_levels = 0;                                       // incoming clouds: up to max_points
+  while (((size_t)kVoxTile << c->map_levels) < cap) ++c->map_levels;
+  c->map_cube_levels = 0;                                  // one 50 m cube: up to 65536 points (more is reported as ALOAM_E_CAPACITY)
+  while (((size_t)kVoxTile << c->map_cube_levels) < std::min<size_t>(pool, 65536)) ++c->map_cube_levels;
   const size_t T = kVoxTile;
   c->map_tile_bound[0] = (int)(B * ((cap + T - 1) / T + (R * 120 + T - 1) / T));
   c->map_tile_bound[1] = (int)(B * (2 * pool / T + 2 * kMapValidMax));
@@ -706,7 +707,7 @@ int aloam_mapping_step(aloam_ctx* c) {
   const MapArgs a = map_args(c);
   { ProfScope p(c, K_MAP_BEGIN); launch_map_begin(a, c->stream); }
   { ProfScope p(c, K_MAP_VOXEL_STACK);                                      // downSizeFilterCorner / Surf on the incoming clouds (:542-550)
-    const VoxArgs v = vox_args(c, c->B * 2);
+    const VoxArgs v = vox_args(c, c->B * 2, c->map_levels);
     launch_map_stack_segments(a, v, c->stream);
     launch_voxel_filter(v, c->map_tile_bound[0], c->stream); }
   { ProfScope p(c, K_MAP_GRID); launch_map_grid(a, c->stream); }            // kdtree*FromMap->setInputCloud (:558-559)
@@ -716,7 +717,7 @@ int aloam_mapping_step(aloam_ctx* c) {
   }
   { ProfScope p(c, K_MAP_INSERT); launch_map_insert(a, c->stream); }        // :737-783
   { ProfScope p(c, K_MAP_VOXEL_CUBES);                                      // per-cube re-filter (:788-801)
-    const VoxArgs v = vox_args(c, c->B * 2 * kMapValidMax);
+    const VoxArgs v = vox_args(c, c->B * 2 * kMapValidMax, c->map_cube_levels);
     launch_map_cube_segments(a, v, c->stream);
     launch_voxel_filter(v, c->map_tile_bound[1], c->stream); }
   { ProfScope p(c, K_MAP_REGISTER); launch_map_register(a, c->stream); }    // :836-846

@@ -1051,7 +1051,7 @@ void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
   hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(1024), 0, s, v);
   hipLaunchKernelGGL(k_vox_bbox, dim3(tile_bound), dim3(256), 0, s, v);
   hipLaunchKernelGGL(k_vox_keys_sort, dim3(tile_bound), dim3(256), 0, s, v);
-  for (int level = 0; level < v.levels; ++level) hipLaunchKernelGGL(k_vox_merge, dim3(tile_bound), dim3(256), 0, s, v, level);
+  for (int level = 0; level < v.levels; ++level) hipLaunchKernelGGL(k_vox_merge, dim3(tile_bound < 4096 ? tile_bound : 4096), dim3(256), 0, s, v, level);
   hipLaunchKernelGGL(k_vox_heads, dim3(tile_bound), dim3(256), 0, s, v);
   hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, s, v);
   hipLaunchKernelGGL(k_vox_emit, dim3(tile_bound), dim3(256), 0, s, v);
