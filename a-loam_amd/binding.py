@@ -21,7 +21,7 @@ CLOUD_FULL, CLOUD_SHARP, CLOUD_LESS_SHARP, CLOUD_FLAT, CLOUD_LESS_FLAT, CLOUD_CO
 E_ARG, E_SCAN_LINES, E_EMPTY, E_CAPACITY, E_HIP, E_STATE = -1, -2, -3, -4, -5, -6
 MAP_REGISTERED, MAP_CORNER_STACK, MAP_SURF_STACK = 2, 3, 4
 MAP_INFO_KEYS = ("cenW", "cenH", "cenD", "frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack",
-                 "corner_num0", "corner_num1", "surf_num0", "surf_num1", "lm_iterations0", "lm_iterations1", "termination0", "termination1")
+                 "corner_num0", "corner_num1", "surf_num0", "surf_num1", "lm_iterations0", "lm_iterations1", "termination0", "compactions")
 
 
 class AloamConfig(C.Structure):

@@ -63,7 +63,7 @@ struct aloam_ctx {
   long long map_key_cap = 0;
   MapSeq* d_mapseq = nullptr; CubeDesc* d_cubes = nullptr; float4* d_pool[2] = {nullptr, nullptr}; int* d_maptab = nullptr;
   float4* d_stack[2] = {nullptr, nullptr}; float4* d_stack_world[2] = {nullptr, nullptr}; int* d_stack_cube[2] = {nullptr, nullptr};
-  int *d_addcnt = nullptr, *d_cursor = nullptr;
+  int *d_addcnt = nullptr, *d_cursor = nullptr, *d_compact_flag = nullptr;
   float4* d_mgrid_sorted[2] = {nullptr, nullptr}; int* d_mgrid_start[2] = {nullptr, nullptr}; int* d_mgrid_cnt[2] = {nullptr, nullptr};
   MapEdgeRec* d_medges = nullptr; MapNormRec* d_mnorms = nullptr; float4* d_registered = nullptr; float4* d_knn = nullptr;
   VoxSeg* d_segs = nullptr; int *d_tile_seg = nullptr, *d_tile_heads = nullptr, *d_tile_pref = nullptr, *d_vox_counters = nullptr, *d_bbox = nullptr;
@@ -296,7 +296,7 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
                   c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
-                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn};
+                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -629,7 +629,7 @@ static MapArgs map_args(aloam_ctx* c) {
     a.pool[k] = c->d_pool[k]; a.stack[k] = c->d_stack[k]; a.stack_world[k] = c->d_stack_world[k]; a.stack_cube[k] = c->d_stack_cube[k];
     a.grid_sorted[k] = c->d_mgrid_sorted[k]; a.grid_start[k] = c->d_mgrid_start[k]; a.grid_cnt[k] = c->d_mgrid_cnt[k]; a.grid_H[k] = c->map_H[k];
   }
-  a.addcnt = c->d_addcnt; a.cursor = c->d_cursor;
+  a.addcnt = c->d_addcnt; a.cursor = c->d_cursor; a.compact_flag = c->d_compact_flag;
   a.edges = c->d_medges; a.norms = c->d_mnorms; a.knn = c->d_knn;
   a.lm_max_iterations = c->cfg.lm_max_iterations;
   return a;
@@ -667,6 +667,7 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   if ((rc = dmalloc(c, &c->d_maptab, B * kTabInts))) return rc;
   if ((rc = dmalloc(c, &c->d_addcnt, B * 2 * kMapCubes))) return rc;
   if ((rc = dmalloc(c, &c->d_cursor, B * 2 * kMapCubes))) return rc;
+  if ((rc = dmalloc(c, &c->d_compact_flag, B * 2))) return rc;
   for (int k = 0; k < 2; ++k) {
     const size_t per = k == 0 ? R * 120 : cap;
     if ((rc = dmalloc(c, &c->d_pool[k], B * pool))) return rc;
@@ -715,7 +716,7 @@ int aloam_mapping_step(aloam_ctx* c) {
     { ProfScope p(c, K_MAP_ASSOC); launch_map_associate(a, iter, c->stream); }
     { ProfScope p(c, K_MAP_SOLVE); launch_map_solve(a, iter, iter == 1, c->stream); }
   }
-  { ProfScope p(c, K_MAP_INSERT); launch_map_insert(a, c->stream); }        // :737-783
+  { ProfScope p(c, K_MAP_INSERT); launch_map_insert(a, c->d_voxtmp, c->stream); }        // :737-783
   { ProfScope p(c, K_MAP_VOXEL_CUBES);                                      // per-cube re-filter (:788-801)
     const VoxArgs v = vox_args(c, c->B * 2 * kMapValidMax, c->map_cube_levels);
     launch_map_cube_segments(a, v, c->stream);
@@ -762,7 +763,7 @@ int aloam_get_map_info(aloam_ctx* c, int seq, int out[16]) {
   if (rc) return rc;
   const int v[16] = {ms.cen[0], ms.cen[1], ms.cen[2], ms.frame_count, ms.from_total[0], ms.from_total[1], ms.n_stack[0], ms.n_stack[1],
                      ms.factor_num[0][0], ms.factor_num[1][0], ms.factor_num[0][1], ms.factor_num[1][1], ms.lm_iterations[0], ms.lm_iterations[1],
-                     ms.lm_termination[0], ms.lm_termination[1]};
+                     ms.lm_termination[0], ms.compactions};
   std::memcpy(out, v, sizeof(v));
   return ALOAM_OK;
 }

@@ -2,6 +2,7 @@
 //
 // Replaces, for a BATCH of independent sequences, the body of process() in the reference's src/laserMapping.cpp:231-893
 // (one frame per call, no frame dropping) and the third-party calls inside it.  Kernel <-> reference map:
+//   k_map_compact_*    (no counterpart: the reference's cubes are std::vectors) packs the class pools when half is handed out
 //   k_map_begin        :142-146 transformAssociateToMap, :311-321 centre cube, :323-507 window shifts (the 21 x 21 x 11
 //                      pointer grid becomes a table of cube descriptors), :509-539 valid cubes + submap prefixes
 //   k_vox_*            pcl::VoxelGrid::filter (:542-550 incoming clouds, :788-801 per-cube re-filter): bounding box ->
@@ -70,6 +71,78 @@ __device__ __forceinline__ float4 submap_point(const MapArgs& a, int b, int cls,
 }
 
 }  // namespace
+
+// =======================================================================================================
+// pool compaction
+// =======================================================================================================
+// Cubes that outgrow their segment move to a fresh one and abandon the old one (k_map_reserve), so a growing map hands out
+// the class pool faster than it fills it.  When the moves of this frame no longer fit behind the bump pointer, the live cubes
+// are packed to the front instead (through a staging buffer, order inside every cube untouched), each with room for this
+// frame's points and half as much again - or, when even that is too much, with exactly the room this frame needs.
+__device__ __forceinline__ int compact_cap(int n, int mode) { return n <= 0 ? 0 : (mode == 1 ? n + n / 2 + 64 : n); }
+
+__global__ __launch_bounds__(256) void k_map_compact_plan(MapArgs a) {
+  const int b = blockIdx.x, cls = blockIdx.y, tid = threadIdx.x;
+  MapSeq& ms = a.seq[b];
+  int* flag = a.compact_flag + b * 2 + cls;
+  const CubeDesc* T = cube_table(a, b, cls);
+  const int* add = a.addcnt + ((long long)b * 2 + cls) * kMapCubes;
+  int* newoff = a.cursor + ((long long)b * 2 + cls) * kMapCubes;
+  __shared__ int s_part[256], s_sum[3];
+  constexpr int PER = (kMapCubes + 255) / 256;
+  if (tid < 3) s_sum[tid] = 0;
+  __syncthreads();
+  int need = 0, roomy = 0, tight = 0;
+  for (int k = 0; k < PER; ++k) {
+    const int c = tid * PER + k;
+    if (c >= kMapCubes) break;
+    const CubeDesc d = T[c];
+    const int ad = add[c], n = d.cnt + (ad > 0 ? ad : 0);
+    if (ad > 0 && n > d.cap) need += 2 * n < 256 ? 256 : 2 * n;            // what k_map_reserve would take
+    roomy += compact_cap(n, 1);
+    tight += compact_cap(n, 2);
+  }
+  if (need) atomicAdd(&s_sum[0], need);
+  if (roomy) { atomicAdd(&s_sum[1], roomy); atomicAdd(&s_sum[2], tight); }
+  __syncthreads();
+  int mode = 0;
+  if (ms.pool_used[cls] + s_sum[0] > a.pool_cap) mode = s_sum[1] <= a.pool_cap ? 1 : (s_sum[2] <= a.pool_cap ? 2 : 0);
+  if (mode == 0) { if (tid == 0) *flag = 0; return; }                       // fits as it is, or really full (k_map_reserve reports that)
+  int local = 0;
+  for (int k = 0; k < PER; ++k) { const int c = tid * PER + k; if (c < kMapCubes) { const int ad = add[c]; local += compact_cap(T[c].cnt + (ad > 0 ? ad : 0), mode); } }
+  s_part[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    const int x = tid >= d ? s_part[tid - d] : 0;
+    __syncthreads();
+    s_part[tid] += x;
+    __syncthreads();
+  }
+  int run = s_part[tid] - local;
+  for (int k = 0; k < PER; ++k) { const int c = tid * PER + k; if (c < kMapCubes) { const int ad = add[c]; newoff[c] = run; run += compact_cap(T[c].cnt + (ad > 0 ? ad : 0), mode); } }
+  if (tid == 0) { *flag = mode; ms.pool_used[cls] = s_part[255]; ms.compactions += 1; }
+}
+
+template <int PHASE>   // 0: cubes -> staging at their new offsets; 1: staging -> pool, descriptors updated
+__global__ __launch_bounds__(256) void k_map_compact_move(MapArgs a, float4* staging) {
+  const int b = blockIdx.y, cls = blockIdx.z, tid = threadIdx.x;
+  const int mode = a.compact_flag[b * 2 + cls];
+  if (!mode) return;
+  CubeDesc* T = cube_table(a, b, cls);
+  const int* add = a.addcnt + ((long long)b * 2 + cls) * kMapCubes;
+  const int* newoff = a.cursor + ((long long)b * 2 + cls) * kMapCubes;
+  float4* pool = a.pool[cls] + (long long)b * a.pool_cap;
+  float4* stage = staging + ((long long)b * 2 + cls) * a.pool_cap;
+  for (int c = blockIdx.x; c < kMapCubes; c += gridDim.x) {
+    const CubeDesc d = T[c];
+    const int no = newoff[c];
+    if (PHASE == 0) { for (int i = tid; i < d.cnt; i += 256) stage[no + i] = pool[d.off + i]; }
+    else {
+      for (int i = tid; i < d.cnt; i += 256) pool[no + i] = stage[no + i];
+      if (tid == 0) { const int ad = add[c]; CubeDesc nd = d; nd.off = no; nd.cap = compact_cap(d.cnt + (ad > 0 ? ad : 0), mode); T[c] = nd; }
+    }
+  }
+}
 
 // =======================================================================================================
 // frame set-up
@@ -1072,8 +1145,11 @@ void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
   hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) { hipLaunchKernelGGL(k_map_solve, dim3(a.B), dim3(kMapSolveThreads), 0, s, a, iter, last ? 1 : 0); }
-void launch_map_insert(const MapArgs& a, hipStream_t s) {
+void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s) {
   hipLaunchKernelGGL(k_map_cubeid, dim3(32, a.B, 2), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_compact_plan, dim3(a.B, 2), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_compact_move<0>, dim3(64, a.B, 2), dim3(256), 0, s, a, staging);
+  hipLaunchKernelGGL(k_map_compact_move<1>, dim3(64, a.B, 2), dim3(256), 0, s, a, staging);
   hipLaunchKernelGGL(k_map_reserve, dim3(a.B, 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_map_scatter, dim3(a.B, 2), dim3(64), 0, s, a);
 }

@@ -27,7 +27,8 @@ struct alignas(16) MapSeq {                              // one per sequence
   int lm_iterations[2], lm_termination[2];
   int pool_used[2];
   int err;
-  int pad[3];
+  int compactions;                                        // pool compactions so far (k_map_compact_*)
+  int pad[2];
 };
 
 struct MapEdgeRec { double cp[3], a[3], b[3]; int valid, pad; };        // LidarEdgeFactor(curr_point, point_a, point_b, 1.0)      (:618)
@@ -77,7 +78,8 @@ struct MapArgs {
   float4* stack_world[2];        // same shapes: the stacks transformed with the refined pose (:739, :762)
   int* stack_cube[2];            // cube index of every stack point, -1 outside the window
   int* addcnt;                   // [B][2][kMapCubes]
-  int* cursor;                   // [B][2][kMapCubes]
+  int* cursor;                   // [B][2][kMapCubes]   append cursors (insertion) / new offsets (compaction)
+  int* compact_flag;             // [B][2]
   float4* grid_sorted[2];        // [B][pool_cap]
   int* grid_start[2];            // [B][H + 1]
   int* grid_cnt[2];              // [B][H]
@@ -96,7 +98,7 @@ void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s);
 void launch_map_grid(const MapArgs& a, hipStream_t s);
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s);
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s);
-void launch_map_insert(const MapArgs& a, hipStream_t s);
+void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s);   // staging: 2 pools per sequence
 void launch_map_register(const MapArgs& a, hipStream_t s);
 
 }  // namespace aloam

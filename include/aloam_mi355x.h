@@ -104,7 +104,7 @@ int aloam_set_full_cloud(aloam_ctx* ctx, int seq, const float* cloud_xyzw, int n
 /* /aft_mapped_to_init pose = q_w_curr, t_w_curr (src/laserMapping.cpp:851-863) and the map<-odom correction (:148-152) */
 int aloam_get_map_pose(aloam_ctx* ctx, int seq, double q_w_curr[4], double t_w_curr[3], double q_wmap_wodom[4], double t_wmap_wodom[3]);
 /* laserCloudCenWidth/Height/Depth, frameCount, submap sizes (corner, surf), stack sizes (corner, surf), factors per iteration
- * (corner[2], surf[2]), LM iterations[2], termination[2] */
+ * (corner[2], surf[2]), LM iterations[2], termination of the first solve, pool compactions so far */
 int aloam_get_map_info(aloam_ctx* ctx, int seq, int out[16]);
 int aloam_map_cube_counts(aloam_ctx* ctx, int seq, int feature_class, int* out_4851);      /* points per cube of the 21 x 21 x 11 window */
 int aloam_get_map_cube(aloam_ctx* ctx, int seq, int feature_class, int cube, float* out_xyzw, int cap_points);   /* laserCloud*Array[cube] */

@@ -192,3 +192,27 @@ def test_full_size_mapping_batch(O, binding, syn):
         gt = Rg[0].T @ (tg[T - 1] - tg[0])
         assert np.linalg.norm(gpu.map_pose(b)["t_w"] - gt) < 0.06, (b, gpu.map_pose(b)["t_w"], gt)
     gpu.close()
+
+
+def test_map_pool_compaction(O, binding):
+    """A map that keeps growing inside one cube outgrows its segment again and again; the abandoned segments would exhaust a
+    small pool.  The automatic compaction must keep the run going and leave the map bit-exact (solver off)."""
+    rng = np.random.default_rng(11)
+    orc = O.Oracle(16, 0.3, lm_max_iterations=0)
+    orc.map_config(0.4, 0.8)
+    gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=1, max_points=8192, lm_max_iterations=0)
+    gpu.mapping_enable(0.4, 0.8, pool_points=40960)
+    for k in range(18):
+        corner = rng.uniform(-10, 10, (1500, 4)).astype(np.float32); corner[:, 3] = rng.integers(0, 16, 1500)
+        surf = rng.uniform(-20, 20, (3000, 4)).astype(np.float32); surf[:, 2] *= 0.01; surf[:, 3] = rng.integers(0, 16, 3000)
+        q, t = np.array([0, 0, 0, 1.0]), np.array([0.01 * k, 0, 0])
+        orc.mapping_step(q, t, corner, surf, surf[:10])
+        gpu.set_last(corner, surf, 0); gpu.set_full_cloud(surf[:10], 0); gpu.set_state([0, 0, 0, 1], [0, 0, 0], q, t, 0)
+        gpu.mapping_step()
+        gpu.synchronize()                                     # raises ALOAM_E_CAPACITY if the pool ran out
+        for cls in (0, 1):
+            _compare_maps(gpu.map_cubes(cls), orc.map_cubes(cls), (k, cls))
+    info = gpu.map_info()
+    assert info["compactions"] >= 1, info
+    assert sum(len(v) for v in gpu.map_cubes(0).values()) > 20480            # more live points than half the pool: doubling alone could not have held them
+    gpu.close()
