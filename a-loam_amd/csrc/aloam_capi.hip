@@ -52,7 +52,7 @@ struct aloam_ctx {
   int* d_grid_start3[2] = {nullptr, nullptr}; int* d_grid_start2[2] = {nullptr, nullptr};
   float4* d_grid_sorted3c[2] = {nullptr, nullptr}; float4* d_grid_sorted2c[2] = {nullptr, nullptr};   // coarse levels
   int* d_grid_start3c[2] = {nullptr, nullptr}; int* d_grid_start2c[2] = {nullptr, nullptr};
-  int* d_grid_first_ge[2] = {nullptr, nullptr}; int* d_grid_last_le[2] = {nullptr, nullptr}; int* d_grid_flags[2] = {nullptr, nullptr};
+  int* d_grid_flags[2] = {nullptr, nullptr};
   int grid_H[2] = {4096, 16384};
   bool grids_valid = false;          // the grids describe the current "last" clouds
   EdgeRec* d_edges = nullptr; PlaneRec* d_planes = nullptr;
@@ -147,7 +147,7 @@ OdomArgs odom_args(aloam_ctx* c) {
     a.grid_sorted3[k] = c->d_grid_sorted3[k]; a.grid_sorted2[k] = c->d_grid_sorted2[k]; a.grid_start3[k] = c->d_grid_start3[k];
     a.grid_sorted3c[k] = c->d_grid_sorted3c[k]; a.grid_sorted2c[k] = c->d_grid_sorted2c[k]; a.grid_start3c[k] = c->d_grid_start3c[k];
     a.grid_start2c[k] = c->d_grid_start2c[k];
-    a.grid_start2[k] = c->d_grid_start2[k]; a.grid_first_ge[k] = c->d_grid_first_ge[k]; a.grid_last_le[k] = c->d_grid_last_le[k];
+    a.grid_start2[k] = c->d_grid_start2[k];
     a.grid_flags[k] = c->d_grid_flags[k];
   }
   a.grid_H_corner = c->grid_H[0]; a.grid_H_surf = c->grid_H[1];
@@ -266,8 +266,6 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
     if ((rc = dmalloc(c, &c->d_grid_sorted2c[k], B * per))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_start3c[k], B * (c->grid_H[k] + 1)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_start2c[k], B * (c->grid_H[k] + 1)))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_first_ge[k], B * (R + 8)))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_last_le[k], B * (R + 8)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_flags[k], B * 4))) return rc;
   }
   if ((rc = dmalloc(c, &c->d_edges, B * R * 12))) return rc;
@@ -290,7 +288,7 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_label, c->d_sharp_idx, c->d_less_sharp_idx, c->d_flat_idx, c->d_pick_cnt, c->d_lf_ring, c->d_lf_cnt, c->d_sharp,
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
-                  c->d_grid_start2[0], c->d_grid_start2[1], c->d_grid_first_ge[0], c->d_grid_first_ge[1], c->d_grid_last_le[0], c->d_grid_last_le[1],
+                  c->d_grid_start2[0], c->d_grid_start2[1],
                   c->d_grid_flags[0], c->d_grid_flags[1], c->d_grid_sorted3c[0], c->d_grid_sorted3c[1], c->d_grid_sorted2c[0], c->d_grid_sorted2c[1],
                   c->d_grid_start3c[0], c->d_grid_start3c[1], c->d_grid_start2c[0], c->d_grid_start2c[1],
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],

@@ -92,9 +92,7 @@ struct OdomArgs {
   float4* grid_sorted2c[2];
   int* grid_start3c[2];      // [B][H+1]
   int* grid_start2c[2];      // [B][H+1]
-  int* grid_first_ge[2];     // [B][R+8]
-  int* grid_last_le[2];      // [B][R+8]
-  int* grid_flags[2];        // [B][4]   flags[0] != 0: cloud not ring-sorted / out of range -> literal brute-force path
+  int* grid_flags[2];        // [B][4]   flags[0] != 0: keys / coordinates out of range -> literal brute-force path; flags[1] != 0: not ring-sorted -> literal walks
   int grid_H_corner, grid_H_surf;   // buckets (power of two, multiple of 1024)
   EdgeRec* edges;            // [B][R*12]
   PlaneRec* planes;          // [B][R*24]
@@ -106,7 +104,7 @@ struct OdomArgs {
 struct GridView {
   int H;
   float4 *sorted3, *sorted2, *sorted3c, *sorted2c;
-  int *start3, *start2, *start3c, *start2c, *first_ge, *last_le, *flags;
+  int *start3, *start2, *start3c, *start2c, *flags;
 };
 __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int which) {
   GridView g;
@@ -120,8 +118,6 @@ __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int whic
   g.sorted2c = a.grid_sorted2c[which] + b * per;
   g.start3c = a.grid_start3c[which] + (long long)b * (g.H + 1);
   g.start2c = a.grid_start2c[which] + (long long)b * (g.H + 1);
-  g.first_ge = a.grid_first_ge[which] + (long long)b * (a.R + 8);
-  g.last_le = a.grid_last_le[which] + (long long)b * (a.R + 8);
   g.flags = a.grid_flags[which] + b * 4;
   return g;
 }

@@ -41,10 +41,10 @@ __device__ __forceinline__ float4 transform_to_start(const float4& p, const Odom
 //   G2: key (ix, iy, ringkey) cell kCell2  — the ring-adjacent second / third neighbour search
 // A grid entry is {x, y, z, bits(idx | (ringkey + 1) << 20)}: one 16-B load per candidate.  Cell sizes are powers
 // of two so p * inv_cell is exact up to the f32 rounding of the product.
-// Also per cloud: first_ge[v] = first index whose ring key (int(intensity)) is >= v, last_le[v] = last index
-// whose key is <= v.  They turn the reference's walk-until-break loops into index windows whenever the cloud is
-// ring-sorted the way scan registration emits it; clouds that are not (possible through aloam_set_last) and
-// clouds with huge coordinates are flagged and served by the literal brute-force path instead.
+// Also per cloud: flags[1] = the cloud is NOT ring-sorted (ring key = int(intensity) never decreasing with the index, the
+// way scan registration emits it).  On ring-sorted clouds the reference's walk-until-break loops visit exactly the points
+// whose key lies within +-2 of the closest point's; clouds that are not sorted (possible through aloam_set_last) take the
+// literal walks, and clouds with huge coordinates or keys (flags[0]) the literal brute-force search as well.
 constexpr float kCell3Surf = 0.5f, kCell3Corner = 1.0f, kCell2 = 1.0f;
 // Coarse levels: a query whose neighbour is not inside the first block of fine cells continues on cells four times as large
 // (3-D) / on 5.25 m cells (ring grid: one 3x3 block then covers the whole DISTANCE_SQ_THRESHOLD = 5 m radius), so the work
@@ -84,12 +84,15 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
   __syncthreads();
   const int is_bad = tab[2 * KT];
   if (tid == 0) {
-    // first_ge[v]: suffix min of first_eq; last_le[v]: prefix max of last_eq.  table index = v + 4, v in [-4, R+3]
-    int run = 0x7fffffff;
-    for (int k = KT - 1; k >= 0; --k) { run = tab[k] < run ? tab[k] : run; g.first_ge[k] = is_bad ? -1 : run; }
-    run = -1;
-    for (int k = 0; k < KT; ++k) { run = tab[KT + k] > run ? tab[KT + k] : run; g.last_le[k] = is_bad ? 0x7fffffff : run; }
+    // ring-sorted (keys never decrease with the index, the way scan registration emits its clouds): every key starts after
+    // all smaller keys have ended.  Then "ring key within cid +- 2" IS the reference's walk-until-break window.
+    int run = -1, unsorted = 0;
+    for (int k = 0; k < KT; ++k) {
+      if (tab[k] != 0x7fffffff && tab[k] < run) unsorted = 1;
+      run = tab[KT + k] > run ? tab[KT + k] : run;
+    }
     g.flags[0] = is_bad;
+    g.flags[1] = unsorted;
   }
   if (is_bad || n == 0) {
     if (n == 0) for (int pass = 0; pass < 4; ++pass) { int* st = pass == 0 ? g.start3 : pass == 1 ? g.start2 : pass == 2 ? g.start3c : g.start2c; for (int h = tid; h <= g.H; h += 1024) st[h] = 0; }
@@ -197,18 +200,28 @@ __device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, in
   }
 }
 
+// A lane's best candidate so far: packed (f32 distance bits << 32 | tie-break order) and the point it belongs to.  After the
+// wave-wide minimum the lane whose own value equals it still holds the winner's coordinates and stores them itself, so no
+// index has to be chased through the cloud afterwards.
+struct Track { unsigned long long v; float x, y, z; };
+__device__ __forceinline__ void track_take(Track& t, bool ok, unsigned long long v, const float4& p) {
+  const bool k = ok && v < t.v;                                             // selects, not branches: the trackers stay in registers
+  t.v = k ? v : t.v; t.x = k ? p.x : t.x; t.y = k ? p.y : t.y; t.z = k ? p.z : t.z;
+}
+
 // Exact 1-NN of `sel` (pcl::KdTreeFLANN::nearestKSearch(k = 1), reference src/laserOdometry.cpp:302,390) by one wave.
-// Returns packed (f32 distance bits << 32 | index), ~0 if nothing was found.  Distances >= 25 are not needed by
-// the caller (DISTANCE_SQ_THRESHOLD), so the grid search stops once every unvisited point is provably >= 5 m away.
-__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int which, const float4* pts, int n, const float4& sel, int lane) {
+// Returns packed (f32 distance bits << 32 | index << 12 | ring key + 1), ~0 if nothing was found; `mine` is this lane's
+// share.  Distances >= 25 are not needed by the caller (DISTANCE_SQ_THRESHOLD), so the grid search stops once every
+// unvisited point is provably >= 5 m away.
+__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool bad, int which, const float4* pts, int n, const float4& sel, int lane, Track& mine) {
   unsigned long long best = ~0ull;
   auto visit = [&](const float4& p) {
     const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
     const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;
-    const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | (__float_as_uint(p.w) & kIdxMask);
-    if (v < best) best = v;
+    const unsigned wb = __float_as_uint(p.w);
+    track_take(mine, true, ((unsigned long long)__float_as_uint(d) << 32) | ((wb & kIdxMask) << 12) | (wb >> 20), p);
   };
-  if (g.flags[0] == 0) {
+  if (!bad) {
     const float cell = cell3_of(which);
     {  // level 0: the 3x3x3 block of fine cells
       const float inv = 1.0f / cell;
@@ -220,7 +233,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int whi
         cnt = g.start3[h + 1] - s0;
       }
       wave_sweep(g.sorted3, s0, cnt, lane, visit);
-      best = wave_min_u64(best);
+      best = wave_min_u64(mine.v);
       const float bound = (1.0f - 0.01f) * cell;                       // every unvisited point is farther than `bound`
       if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= bound * bound) return best;
     }
@@ -242,7 +255,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int whi
         }
         wave_sweep(g.sorted3c, s0, cnt, lane, visit);
       }
-      best = wave_min_u64(best);
+      best = wave_min_u64(mine.v);
       const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
       if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= b2) break;
       if (b2 >= 25.0f) break;                                         // nothing within DISTANCE_SQ_THRESHOLD is left
@@ -256,7 +269,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int whi
       visit(make_float4(p.x, p.y, p.z, __uint_as_float((unsigned)j)));
     }
   }
-  return wave_min_u64(best);
+  return wave_min_u64(mine.v);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -265,6 +278,9 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, int whi
 //   PLANE = true : planar features  (reference src/laserOdometry.cpp:387-483)  -> PlaneRec
 // Candidates of the ring walk are ordered exactly as the reference visits them (upward from closest+1, then
 // downward from closest-1); "first strictly smaller wins" is the lexicographic (distance, visit order) minimum.
+// The kernel is a chain of dependent memory round trips per query (bucket bounds -> bucket entries, twice), so everything
+// that does not depend on a search result is loaded up front and nothing is fetched by index afterwards: grid entries
+// carry their ring key, and the lanes that saw the winners store the record fields themselves.
 template <bool PLANE>
 __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs by linear id and every XCD has its
@@ -275,22 +291,25 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   const int b = (slot / (int)gridDim.x) * 8 + xcd, lane = threadIdx.x & 63;
   if (b >= a.B) return;
   const int qi = (slot % (int)gridDim.x) * 4 + (threadIdx.x >> 6);
+  const int qcap = PLANE ? a.R * 24 : a.R * 12;
+  const float4* Q = (PLANE ? a.flat : a.sharp) + (long long)b * qcap;
+  const float4 raw = Q[qi < qcap ? qi : qcap - 1];                      // issued together with the scalar loads below
   const SeqMeta m = a.meta[b];
+  const GridView g = grid_view(a, b, PLANE ? 1 : 0);
+  const bool bad = g.flags[0] != 0, unsorted = g.flags[1] != 0;
+  const float4 sel = transform_to_start(raw, a.state[b]);
   const int nq = PLANE ? m.n_flat : m.n_sharp;
   if (qi >= nq) return;
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
   const float4* T = PLANE ? a.surf_last + (long long)b * a.cap : a.corner_last + (long long)b * a.R * 120;
-  const float4 raw = PLANE ? a.flat[(long long)b * a.R * 24 + qi] : a.sharp[(long long)b * a.R * 12 + qi];
-  const GridView g = grid_view(a, b, PLANE ? 1 : 0);
-  const float4 sel = transform_to_start(raw, a.state[b]);
-  int valid = 0, closest = -1, min2 = -1, min3 = -1;
-  const unsigned long long nn = nt > 0 ? wave_nn(g, PLANE ? 1 : 0, T, nt, sel, lane) : ~0ull;
+  int valid = 0;
+  Track t1 = {~0ull, 0.f, 0.f, 0.f}, t2 = t1, t3 = t1;
+  unsigned long long best2 = ~0ull, best3 = ~0ull;
+  const unsigned long long nn = nt > 0 ? wave_nn(g, bad, PLANE ? 1 : 0, T, nt, sel, lane, t1) : ~0ull;
   const float nnd = __uint_as_float((unsigned)(nn >> 32));
   if (nn != ~0ull && (double)nnd < 25.0) {                            // DISTANCE_SQ_THRESHOLD (:65,305,393)
-    closest = (int)(unsigned)nn;
-    const int cid = (int)T[closest].w;                                // closestPointScanID (:308,398)
-    unsigned long long best2 = ~0ull, best3 = ~0ull;
-    const int jup = g.first_ge[cid + 3 + 4], jdown = g.last_le[cid - 3 + 4];
+    const int closest = (int)((unsigned)nn >> 12);
+    const int cid = bad ? (int)T[closest].w : (int)((unsigned)nn & 0xfffu) - 1;     // closestPointScanID (:308,398)
     auto consider = [&](const float4& p, int j, int key) {
       if (j == closest) return;
       const bool up = j > closest;
@@ -301,15 +320,15 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
       if (!((double)d < 25.0)) return;
       const unsigned seq = up ? (unsigned)(j - closest) : 0x40000000u + (unsigned)(closest - j);
       const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | seq;
-      if (c2 && v < best2) best2 = v;
-      if (c3 && v < best3) best3 = v;
+      track_take(t2, c2, v, p);
+      if (PLANE) track_take(t3, c3, v, p);
     };
-    if (g.flags[0] == 0 && jup > closest && jdown < closest) {
-      // window form: candidates are exactly the indices (jdown, jup) \ {closest}; their keys lie in cid-2 .. cid+2
+    if (!bad && !unsorted) {
+      // window form: the walks visit exactly the points whose ring key lies in cid-2 .. cid+2 (minus the closest point)
       auto visit = [&](const float4& p) {
         const unsigned wb = __float_as_uint(p.w);
         const int j = (int)(wb & kIdxMask), pk = (int)(wb >> 20) - 1;
-        if (j > jdown && j < jup) consider(p, j, pk);
+        if (pk >= cid - 2 && pk <= cid + 2) consider(p, j, pk);
       };
       // level 0: the 3x3 block of fine cells, 5 ring keys each (45 look-ups, one per lane); level 1, only if a neighbour may
       // still be farther than the fine block reaches: the 3x3 block of coarse cells, which covers DISTANCE_SQ_THRESHOLD
@@ -328,8 +347,8 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
           }
         }
         wave_sweep(so, s0, cnt, lane, visit);
-        best2 = wave_min_u64(best2);
-        if (PLANE) best3 = wave_min_u64(best3);
+        best2 = wave_min_u64(t2.v);
+        if (PLANE) best3 = wave_min_u64(t3.v);
         const float bound = (1.0f - 0.01f) * cell, b2 = bound * bound;
         if (b2 >= 25.0f) break;
         const bool done2 = best2 != ~0ull && __uint_as_float((unsigned)(best2 >> 32)) <= b2;
@@ -360,45 +379,35 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
         if (j >= 0 && lane < first_stop) consider(p, j, key);
         if (sm) break;
       }
-      best2 = wave_min_u64(best2);
-      if (PLANE) best3 = wave_min_u64(best3);
+      best2 = wave_min_u64(t2.v);
+      if (PLANE) best3 = wave_min_u64(t3.v);
     }
-    auto decode = [&](unsigned long long v) {
-      const unsigned seq = (unsigned)v;
-      return seq >= 0x40000000u ? closest - (int)(seq - 0x40000000u) : closest + (int)seq;
-    };
-    if (best2 != ~0ull && (!PLANE || best3 != ~0ull)) {                 // :363 / :457
-      min2 = decode(best2);
-      if (PLANE) min3 = decode(best3);
-      valid = 1;
-    }
+    valid = best2 != ~0ull && (!PLANE || best3 != ~0ull);               // :363 / :457
   }
-  if (lane == 0) {
-    if (PLANE) {
-      PlaneRec e;
-      e.valid = valid;
-      e.pad[0] = e.pad[1] = e.pad[2] = 0;
-      e.cp[0] = raw.x; e.cp[1] = raw.y; e.cp[2] = raw.z;               // raw, untransformed point (:460-462)
-      for (int k = 0; k < 3; ++k) e.j[k] = e.l[k] = e.m[k] = 0.f;
-      if (valid) {
-        const float4 pj = T[closest], pl = T[min2], pm = T[min3];
-        e.j[0] = pj.x; e.j[1] = pj.y; e.j[2] = pj.z;
-        e.l[0] = pl.x; e.l[1] = pl.y; e.l[2] = pl.z;
-        e.m[0] = pm.x; e.m[1] = pm.y; e.m[2] = pm.z;
-      }
-      a.planes[(long long)b * a.R * 24 + qi] = e;
-    } else {
-      EdgeRec e;
-      e.valid = valid;
-      e.pad[0] = e.pad[1] = 0;
-      e.cp[0] = raw.x; e.cp[1] = raw.y; e.cp[2] = raw.z;               // raw, untransformed point (:365-367)
-      for (int k = 0; k < 3; ++k) e.a[k] = e.b[k] = 0.f;
-      if (valid) {
-        const float4 pa = T[closest], pb = T[min2];
-        e.a[0] = pa.x; e.a[1] = pa.y; e.a[2] = pa.z;
-        e.b[0] = pb.x; e.b[1] = pb.y; e.b[2] = pb.z;
-      }
-      a.edges[(long long)b * a.R * 12 + qi] = e;
+  // the record: lane 0 stores the raw, untransformed point (:365-367 / :460-462) and the flag, the lanes that saw the
+  // winners store them (a point seen on two grid levels is stored twice with the same value)
+  if (PLANE) {
+    PlaneRec* e = a.planes + (long long)b * a.R * 24 + qi;
+    if (lane == 0) {
+      e->cp[0] = raw.x; e->cp[1] = raw.y; e->cp[2] = raw.z;
+      e->valid = valid; e->pad[0] = e->pad[1] = e->pad[2] = 0;
+      if (!valid) for (int k = 0; k < 3; ++k) e->j[k] = e->l[k] = e->m[k] = 0.f;
+    }
+    if (valid) {
+      if (t1.v == nn) { e->j[0] = t1.x; e->j[1] = t1.y; e->j[2] = t1.z; }
+      if (t2.v == best2) { e->l[0] = t2.x; e->l[1] = t2.y; e->l[2] = t2.z; }
+      if (t3.v == best3) { e->m[0] = t3.x; e->m[1] = t3.y; e->m[2] = t3.z; }
+    }
+  } else {
+    EdgeRec* e = a.edges + (long long)b * a.R * 12 + qi;
+    if (lane == 0) {
+      e->cp[0] = raw.x; e->cp[1] = raw.y; e->cp[2] = raw.z;
+      e->valid = valid; e->pad[0] = e->pad[1] = 0;
+      if (!valid) for (int k = 0; k < 3; ++k) e->a[k] = e->b[k] = 0.f;
+    }
+    if (valid) {
+      if (t1.v == nn) { e->a[0] = t1.x; e->a[1] = t1.y; e->a[2] = t1.z; }
+      if (t2.v == best2) { e->b[0] = t2.x; e->b[1] = t2.y; e->b[2] = t2.z; }
     }
   }
 }
