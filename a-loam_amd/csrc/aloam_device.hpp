@@ -249,6 +249,23 @@ __device__ __forceinline__ unsigned long long wave_extreme_u64(unsigned long lon
   return best;                                                                // wave-uniform
 }
 
+// Inclusive wave64 scans on the DPP network (no LDS crossbar): Hillis-Steele inside each row of 16 lanes, then the row
+// totals travel with row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).  `identity` fills the lanes a shift
+// leaves without a source.
+template <bool MAX>
+__device__ __forceinline__ int wave_scan_i32(int v) {
+  constexpr int identity = MAX ? (int)0x80000000 : 0;
+  auto op = [](int a, int b) { return MAX ? (a > b ? a : b) : a + b; };
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xF, 0xF, false));   // row_shr:1
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xF, 0xF, false));   // row_shr:2
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xF, 0xF, false));   // row_shr:4
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xF, 0xF, false));   // row_shr:8
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+
 // LDS bitonic sort of npad (power of two) 64-bit keys, ascending, 256 threads.
 __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int npad, int tid) {
   for (int k = 2; k <= npad; k <<= 1) {

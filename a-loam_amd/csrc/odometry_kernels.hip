@@ -178,26 +178,51 @@ __device__ __forceinline__ void shell3d(int r, int c, int* dx, int* dy, int* dz)
 }
 
 // Load-balanced sweep over the buckets the lanes looked up: lane L owns bucket [s0, s0 + cnt); all 64 lanes then share
-// the concatenated candidate list (exclusive prefix by shuffles, owner found by a 6-step binary search over the
-// prefix through ds_bpermute), so every candidate costs one independent 16-B load instead of a per-lane serial chain.
+// the concatenated candidate list, so every candidate costs one independent 16-B load instead of a per-lane serial chain.
+// Position i belongs to the last lane whose exclusive prefix is <= i: the owners drop their lane id at their first position
+// in a 64-entry LDS row of the wave and an inclusive max-scan spreads it (prefix and spread run on the DPP network; the only
+// LDS round trips per 64 candidates are that row and the two bpermutes that fetch the owner's bucket).
 template <class F>
-__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, F&& f) {
-  int incl = cnt;
-  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-  const int total = __shfl(incl, 63, 64);
+__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f) {
+  const int incl = wave_scan_i32<false>(cnt);
+  const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
-  for (int base = 0; base < total; base += 64) {
-    const int i = base + lane;
-    int lo = 0, hi = 63;
-#pragma unroll
-    for (int step = 0; step < 6; ++step) {
-      const int mid = (lo + hi + 1) >> 1;
-      const int e = __shfl(excl, mid, 64);
-      if (e <= i) lo = mid; else hi = mid - 1;
-    }
-    const int os = __shfl(s0, lo, 64), oe = __shfl(excl, lo, 64);
-    if (i < total) f(sorted[os + (i - oe)]);
+  int carry = 0;                                                           // owner + 1 of the position before `base`
+  for (int base = 0; base < total; base += 128) {                          // two independent loads in flight per lane
+    const int slot = excl - base;
+    const bool two = base + 64 < total;
+    row[lane] = 0;
+    if (two) row[64 + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (cnt > 0 && slot >= 0 && slot < (two ? 128 : 64)) row[slot] = lane + 1;
+    __builtin_amdgcn_wave_barrier();
+    int own0 = row[lane], own1 = two ? row[64 + lane] : 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && carry > own0) own0 = carry;
+    own0 = wave_scan_i32<true>(own0);
+    carry = __builtin_amdgcn_readlane(own0, 63);
+    const int i0 = base + lane, i1 = i0 + 64;
+    const int os0 = __shfl(s0, own0 - 1, 64), oe0 = __shfl(excl, own0 - 1, 64);
+    const float4 p0 = sorted[i0 < total ? os0 + (i0 - oe0) : 0];
+    if (two) {
+      if (lane == 0 && carry > own1) own1 = carry;
+      own1 = wave_scan_i32<true>(own1);
+      carry = __builtin_amdgcn_readlane(own1, 63);
+      const int os1 = __shfl(s0, own1 - 1, 64), oe1 = __shfl(excl, own1 - 1, 64);
+      const float4 p1 = sorted[i1 < total ? os1 + (i1 - oe1) : 0];
+      if (i0 < total) f(p0);
+      if (i1 < total) f(p1);
+    } else if (i0 < total) f(p0);
   }
+}
+
+// Distance from coordinate s to the cell [c * cell, (c + 1) * cell) along one axis (0 inside).  Points are
+// binned with floorf(p / cell); the gap is shortened by 1 mm and callers leave another 0.1 % on the squared distance, so a
+// skipped cell provably holds nothing that could tie with or beat the current best.
+__device__ __forceinline__ float cell_gap(float s, int c, float cell) {
+  const float lo = (float)c * cell, hi = lo + cell;
+  const float gap = s < lo ? lo - s : (s > hi ? s - hi : 0.f);
+  return gap > 1e-3f ? gap - 1e-3f : 0.f;                                 // 1 mm: far above the rounding of p / cell for |p| < 4096
 }
 
 // A lane's best candidate so far: packed (f32 distance bits << 32 | tie-break order) and the point it belongs to.  After the
@@ -213,7 +238,7 @@ __device__ __forceinline__ void track_take(Track& t, bool ok, unsigned long long
 // Returns packed (f32 distance bits << 32 | index << 12 | ring key + 1), ~0 if nothing was found; `mine` is this lane's
 // share.  Distances >= 25 are not needed by the caller (DISTANCE_SQ_THRESHOLD), so the grid search stops once every
 // unvisited point is provably >= 5 m away.
-__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool bad, int which, const float4* pts, int n, const float4& sel, int lane, Track& mine) {
+__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool bad, int which, const float4* pts, int n, const float4& sel, int lane, int* row, Track& mine) {
   unsigned long long best = ~0ull;
   auto visit = [&](const float4& p) {
     const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
@@ -232,7 +257,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
         s0 = g.start3[h];
         cnt = g.start3[h + 1] - s0;
       }
-      wave_sweep(g.sorted3, s0, cnt, lane, visit);
+      wave_sweep(g.sorted3, s0, cnt, lane, row, visit);
       best = wave_min_u64(mine.v);
       const float bound = (1.0f - 0.01f) * cell;                       // every unvisited point is farther than `bound`
       if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= bound * bound) return best;
@@ -242,6 +267,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
     const int ux = (int)floorf(sel.x * invc), uy = (int)floorf(sel.y * invc), uz = (int)floorf(sel.z * invc);
     for (int r = 1;; ++r) {
       const int ncell = r == 1 ? 27 : 24 * r * r + 2;
+      const float limit = best != ~0ull ? fminf(__uint_as_float((unsigned)(best >> 32)), 25.0f) : 25.0f;
       for (int cb = 0; cb < ncell; cb += 64) {
         const int c = cb + lane;
         int s0 = 0, cnt = 0;
@@ -249,11 +275,15 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
           int dx, dy, dz;
           if (r == 1) { dz = c / 9 - 1; dy = (c % 9) / 3 - 1; dx = c % 3 - 1; }
           else shell3d(r, c, &dx, &dy, &dz);
-          const unsigned h = hash3(ux + dx, uy + dy, uz + dz) & (unsigned)(g.H - 1);
-          s0 = g.start3c[h];
-          cnt = g.start3c[h + 1] - s0;
+          // a cell farther away than the best candidate so far (or than DISTANCE_SQ_THRESHOLD) cannot change the answer
+          const float gx = cell_gap(sel.x, ux + dx, cellc), gy = cell_gap(sel.y, uy + dy, cellc), gz = cell_gap(sel.z, uz + dz, cellc);
+          if (((gx * gx + gy * gy) + gz * gz) * 0.999f <= limit) {
+            const unsigned h = hash3(ux + dx, uy + dy, uz + dz) & (unsigned)(g.H - 1);
+            s0 = g.start3c[h];
+            cnt = g.start3c[h + 1] - s0;
+          }
         }
-        wave_sweep(g.sorted3c, s0, cnt, lane, visit);
+        wave_sweep(g.sorted3c, s0, cnt, lane, row, visit);
       }
       best = wave_min_u64(mine.v);
       const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
@@ -290,6 +320,8 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, slot = L >> 3;
   const int b = (slot / (int)gridDim.x) * 8 + xcd, lane = threadIdx.x & 63;
   if (b >= a.B) return;
+  __shared__ int s_row[4][128];
+  int* row = s_row[threadIdx.x >> 6];
   const int qi = (slot % (int)gridDim.x) * 4 + (threadIdx.x >> 6);
   const int qcap = PLANE ? a.R * 24 : a.R * 12;
   const float4* Q = (PLANE ? a.flat : a.sharp) + (long long)b * qcap;
@@ -305,7 +337,7 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   int valid = 0;
   Track t1 = {~0ull, 0.f, 0.f, 0.f}, t2 = t1, t3 = t1;
   unsigned long long best2 = ~0ull, best3 = ~0ull;
-  const unsigned long long nn = nt > 0 ? wave_nn(g, bad, PLANE ? 1 : 0, T, nt, sel, lane, t1) : ~0ull;
+  const unsigned long long nn = nt > 0 ? wave_nn(g, bad, PLANE ? 1 : 0, T, nt, sel, lane, row, t1) : ~0ull;
   const float nnd = __uint_as_float((unsigned)(nn >> 32));
   if (nn != ~0ull && (double)nnd < 25.0) {                            // DISTANCE_SQ_THRESHOLD (:65,305,393)
     const int closest = (int)((unsigned)nn >> 12);
@@ -332,6 +364,10 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
       };
       // level 0: the 3x3 block of fine cells, 5 ring keys each (45 look-ups, one per lane); level 1, only if a neighbour may
       // still be farther than the fine block reaches: the 3x3 block of coarse cells, which covers DISTANCE_SQ_THRESHOLD
+      // On a ring-sorted cloud the second neighbour of a planar feature is the nearest point of the closest point's own ring
+      // and the third the nearest of the other rings; a corner feature's second neighbour comes from the other rings only.
+      bool done2 = false, done3 = !PLANE;
+      float lim2 = 25.0f, lim3 = 25.0f;
       for (int level = 0; level < 2; ++level) {
         const float cell = level == 0 ? kCell2 : kCell2Coarse, inv = 1.0f / cell;
         const int* st = level == 0 ? g.start2 : g.start2c;
@@ -339,20 +375,25 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
         const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv);
         int s0 = 0, cnt = 0;
         if (lane < 45) {
-          const int key = cid + lane % 5 - 2, cc = lane / 5;
-          if (key >= 0) {
-            const unsigned h = hash3(cx + cc % 3 - 1, cy + cc / 3 - 1, key) & (unsigned)(g.H - 1);
+          const int key = cid + lane % 5 - 2, cc = lane / 5, ix = cx + cc % 3 - 1, iy = cy + cc / 3 - 1;
+          const bool second = PLANE ? key == cid : key != cid;
+          const bool wanted = second ? !done2 : (PLANE && !done3);
+          const float gx = cell_gap(sel.x, ix, cell), gy = cell_gap(sel.y, iy, cell);
+          if (key >= 0 && wanted && (gx * gx + gy * gy) * 0.999f <= (second ? lim2 : lim3)) {
+            const unsigned h = hash3(ix, iy, key) & (unsigned)(g.H - 1);
             s0 = st[h];
             cnt = st[h + 1] - s0;
           }
         }
-        wave_sweep(so, s0, cnt, lane, visit);
+        wave_sweep(so, s0, cnt, lane, row, visit);
         best2 = wave_min_u64(t2.v);
         if (PLANE) best3 = wave_min_u64(t3.v);
         const float bound = (1.0f - 0.01f) * cell, b2 = bound * bound;
         if (b2 >= 25.0f) break;
-        const bool done2 = best2 != ~0ull && __uint_as_float((unsigned)(best2 >> 32)) <= b2;
-        const bool done3 = !PLANE || (best3 != ~0ull && __uint_as_float((unsigned)(best3 >> 32)) <= b2);
+        if (best2 != ~0ull) lim2 = __uint_as_float((unsigned)(best2 >> 32));
+        if (PLANE && best3 != ~0ull) lim3 = __uint_as_float((unsigned)(best3 >> 32));
+        done2 = best2 != ~0ull && lim2 <= b2;
+        done3 = !PLANE || (best3 != ~0ull && lim3 <= b2);
         if (done2 && done3) break;
       }
     } else {
