@@ -66,38 +66,19 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
   extern __shared__ __attribute__((aligned(16))) int lds[];
   int* cnt = lds;                         // [H]
   int* part = lds + g.H;                  // [1024]
-  int* tab = part + 1024;                 // first_eq [KT], last_eq [KT], flags[4]
-  const int KT = a.R + 8;
-  for (int k = tid; k < KT; k += 1024) { tab[k] = 0x7fffffff; tab[KT + k] = -1; }
-  if (tid < 4) tab[2 * KT + tid] = 0;
-  __syncthreads();
-  // pass 0: ring-key tables + sanity flags
-  int bad = 0;
-  for (int i = tid; i < n; i += 1024) {
-    const float4 p = pts[i];
-    const int key = (int)p.w;
-    if (key < 0 || key > a.R || !(fabsf(p.x) < 4096.f && fabsf(p.y) < 4096.f && fabsf(p.z) < 4096.f)) bad = 1;
-    else { atomicMin(&tab[key + 4], i); atomicMax(&tab[KT + key + 4], i); }
-  }
-  if (bad) atomicOr(&tab[2 * KT], 1);
-  if (n >= (1 << 20)) tab[2 * KT] = 1;
-  __syncthreads();
-  const int is_bad = tab[2 * KT];
-  if (tid == 0) {
-    // ring-sorted (keys never decrease with the index, the way scan registration emits its clouds): every key starts after
-    // all smaller keys have ended.  Then "ring key within cid +- 2" IS the reference's walk-until-break window.
-    int run = -1, unsorted = 0;
-    for (int k = 0; k < KT; ++k) {
-      if (tab[k] != 0x7fffffff && tab[k] < run) unsorted = 1;
-      run = tab[KT + k] > run ? tab[KT + k] : run;
-    }
-    g.flags[0] = is_bad;
-    g.flags[1] = unsorted;
-  }
-  if (is_bad || n == 0) {
-    if (n == 0) for (int pass = 0; pass < 4; ++pass) { int* st = pass == 0 ? g.start3 : pass == 1 ? g.start2 : pass == 2 ? g.start3c : g.start2c; for (int h = tid; h <= g.H; h += 1024) st[h] = 0; }
+  int* s_flag = part + 1024;              // bad, unsorted
+  if (tid < 2) s_flag[tid] = n >= (1 << 20) && tid == 0 ? 1 : 0;
+  if (n == 0) {
+    for (int pass = 0; pass < 4; ++pass) { int* st = pass == 0 ? g.start3 : pass == 1 ? g.start2 : pass == 2 ? g.start3c : g.start2c; for (int h = tid; h <= g.H; h += 1024) st[h] = 0; }
+    if (tid < 2) g.flags[tid] = 0;
     return;
   }
+  // The loops below keep the loads of the next round in flight while the current one is binned: on this ISA a wait for
+  // loaded data also waits for every older store, so loads are always issued ahead of the stores they must not wait for.
+  auto fetch = [&](int base, float4* p) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; p[u] = pts[i < n ? i : n - 1]; }
+  };
   for (int pass = 0; pass < 4; ++pass) {          // 0: G3, 1: G2, 2: G3 coarse, 3: G2 coarse
     const bool g3 = (pass & 1) == 0;
     const float cell = pass == 0 ? cell3_of(which) : pass == 1 ? kCell2 : pass == 2 ? cell3_of(which) * kCell3CoarseFactor : kCell2Coarse;
@@ -107,19 +88,44 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
     __syncthreads();
     for (int h = tid; h < g.H; h += 1024) cnt[h] = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 4096) {            // four independent loads in flight per thread
-      float4 p[4];
+    float4 p[4], pn[4];
+    float pw[4], pwn[4];                          // pass 0: intensity of the point before, for the ring-sorted test
+    fetch(0, p);
+    if (pass == 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; p[u] = pts[i < n ? i : n - 1]; }
+      for (int u = 0; u < 4; ++u) { const int i = u * 1024 + tid; pw[u] = pts[i < n ? (i > 0 ? i - 1 : 0) : n - 1].w; }
+    }
+    int bad = 0, unsorted = 0;
+    for (int base = 0; base < n; base += 4096) {
+      if (base + 4096 < n) {
+        fetch(base + 4096, pn);
+        if (pass == 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int i = base + 4096 + u * 1024 + tid; pwn[u] = pts[i < n ? i - 1 : n - 1].w; }
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (base + u * 1024 + tid >= n) continue;
+        const int key = (int)p[u].w;
+        if (pass == 0) {
+          // sanity: ring keys 0..R and coordinates the cell arithmetic is exact for; ring-sorted: keys never decrease
+          if (key < 0 || key > a.R || !(fabsf(p[u].x) < 4096.f && fabsf(p[u].y) < 4096.f && fabsf(p[u].z) < 4096.f)) bad = 1;
+          if (key < (int)pw[u]) unsorted = 1;
+        }
         const int ix = (int)floorf(p[u].x * inv), iy = (int)floorf(p[u].y * inv);
-        const int iz = g3 ? (int)floorf(p[u].z * inv) : (int)p[u].w;
+        const int iz = g3 ? (int)floorf(p[u].z * inv) : key;
         atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { p[u] = pn[u]; pw[u] = pwn[u]; }
+    }
+    if (pass == 0) {
+      if (bad) atomicOr(&s_flag[0], 1);
+      if (unsorted) atomicOr(&s_flag[1], 1);
     }
     __syncthreads();
+    if (pass == 0 && tid < 2) g.flags[tid] = s_flag[tid];
     // exclusive scan of cnt[H]: per-thread run of H/1024 consecutive buckets + scan of the 1024 partial sums
     const int per = g.H / 1024;
     int local = 0;
@@ -136,10 +142,9 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
     for (int k = 0; k < per; ++k) { const int c = cnt[tid * per + k]; cnt[tid * per + k] = run; start[tid * per + k] = run; run += c; }
     if (tid == 1023) start[g.H] = run;
     __syncthreads();
+    fetch(0, p);
     for (int base = 0; base < n; base += 4096) {
-      float4 p[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; p[u] = pts[i < n ? i : n - 1]; }
+      if (base + 4096 < n) fetch(base + 4096, pn);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = base + u * 1024 + tid;
@@ -150,6 +155,8 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
         const int pos = atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
         sorted[pos] = make_float4(p[u].x, p[u].y, p[u].z, __uint_as_float((unsigned)i | ((unsigned)(key + 1) << 20)));
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = pn[u];
     }
   }
 }
