@@ -189,8 +189,12 @@ __device__ __forceinline__ void shell3d(int r, int c, int* dx, int* dy, int* dz)
 // Position i belongs to the last lane whose exclusive prefix is <= i: the owners drop their lane id at their first position
 // in a 64-entry LDS row of the wave and an inclusive max-scan spreads it (prefix and spread run on the DPP network; the only
 // LDS round trips per 64 candidates are that row and the two bpermutes that fetch the owner's bucket).
+// What a lane still holds of a sweep that needed a single round (<= 128 candidates): the caller can look at the same
+// candidates again under another criterion without touching memory.
+struct Kept { float4 p0, p1; bool ok, a0, a1; };
+
 template <class F>
-__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f) {
+__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f, Kept* keep = nullptr) {
   const int incl = wave_scan_i32<false>(cnt);
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
@@ -211,16 +215,19 @@ __device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, in
     const int i0 = base + lane, i1 = i0 + 64;
     const int os0 = __shfl(s0, own0 - 1, 64), oe0 = __shfl(excl, own0 - 1, 64);
     const float4 p0 = sorted[i0 < total ? os0 + (i0 - oe0) : 0];
+    if (keep) { keep->p0 = p0; keep->a0 = i0 < total; keep->a1 = false; }
     if (two) {
       if (lane == 0 && carry > own1) own1 = carry;
       own1 = wave_scan_i32<true>(own1);
       carry = __builtin_amdgcn_readlane(own1, 63);
       const int os1 = __shfl(s0, own1 - 1, 64), oe1 = __shfl(excl, own1 - 1, 64);
       const float4 p1 = sorted[i1 < total ? os1 + (i1 - oe1) : 0];
+      if (keep) { keep->p1 = p1; keep->a1 = i1 < total; }
       if (i0 < total) f(p0);
       if (i1 < total) f(p1);
     } else if (i0 < total) f(p0);
   }
+  if (keep) keep->ok = total <= 128;
 }
 
 // Distance from coordinate s to the cell [c * cell, (c + 1) * cell) along one axis (0 inside).  Points are
@@ -245,7 +252,7 @@ __device__ __forceinline__ void track_take(Track& t, bool ok, unsigned long long
 // Returns packed (f32 distance bits << 32 | index << 12 | ring key + 1), ~0 if nothing was found; `mine` is this lane's
 // share.  Distances >= 25 are not needed by the caller (DISTANCE_SQ_THRESHOLD), so the grid search stops once every
 // unvisited point is provably >= 5 m away.
-__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool bad, int which, const float4* pts, int n, const float4& sel, int lane, int* row, Track& mine) {
+__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool bad, int which, const float4* pts, int n, const float4& sel, int lane, int* row, Track& mine, Kept& kept) {
   unsigned long long best = ~0ull;
   auto visit = [&](const float4& p) {
     const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
@@ -264,7 +271,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
         s0 = g.start3[h];
         cnt = g.start3[h + 1] - s0;
       }
-      wave_sweep(g.sorted3, s0, cnt, lane, row, visit);
+      wave_sweep(g.sorted3, s0, cnt, lane, row, visit, &kept);
       best = wave_min_u64(mine.v);
       const float bound = (1.0f - 0.01f) * cell;                       // every unvisited point is farther than `bound`
       if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= bound * bound) return best;
@@ -343,8 +350,11 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   const float4* T = PLANE ? a.surf_last + (long long)b * a.cap : a.corner_last + (long long)b * a.R * 120;
   int valid = 0;
   Track t1 = {~0ull, 0.f, 0.f, 0.f}, t2 = t1, t3 = t1;
+  Kept kept;
+  kept.ok = kept.a0 = kept.a1 = false;
+  kept.p0 = kept.p1 = make_float4(0.f, 0.f, 0.f, 0.f);
   unsigned long long best2 = ~0ull, best3 = ~0ull;
-  const unsigned long long nn = nt > 0 ? wave_nn(g, bad, PLANE ? 1 : 0, T, nt, sel, lane, row, t1) : ~0ull;
+  const unsigned long long nn = nt > 0 ? wave_nn(g, bad, PLANE ? 1 : 0, T, nt, sel, lane, row, t1, kept) : ~0ull;
   const float nnd = __uint_as_float((unsigned)(nn >> 32));
   if (nn != ~0ull && (double)nnd < 25.0) {                            // DISTANCE_SQ_THRESHOLD (:65,305,393)
     const int closest = (int)((unsigned)nn >> 12);
@@ -375,7 +385,20 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
       // and the third the nearest of the other rings; a corner feature's second neighbour comes from the other rings only.
       bool done2 = false, done3 = !PLANE;
       float lim2 = 25.0f, lim3 = 25.0f;
-      for (int level = 0; level < 2; ++level) {
+      if (kept.ok) {
+        // The candidates of the fine 1-NN block are still in registers: every point within (almost) one cell of the query is
+        // among them, so neighbours found there within that radius are final and the ring grid is not needed for them.
+        if (kept.a0) visit(kept.p0);
+        if (kept.a1) visit(kept.p1);
+        best2 = wave_min_u64(t2.v);
+        if (PLANE) best3 = wave_min_u64(t3.v);
+        const float bound = (1.0f - 0.01f) * cell3_of(PLANE ? 1 : 0), b2 = bound * bound;
+        if (best2 != ~0ull) lim2 = __uint_as_float((unsigned)(best2 >> 32));
+        if (PLANE && best3 != ~0ull) lim3 = __uint_as_float((unsigned)(best3 >> 32));
+        done2 = best2 != ~0ull && lim2 <= b2;
+        done3 = !PLANE || (best3 != ~0ull && lim3 <= b2);
+      }
+      for (int level = 0; level < 2 && !(done2 && done3); ++level) {
         const float cell = level == 0 ? kCell2 : kCell2Coarse, inv = 1.0f / cell;
         const int* st = level == 0 ? g.start2 : g.start2c;
         const float4* so = level == 0 ? g.sorted2 : g.sorted2c;
