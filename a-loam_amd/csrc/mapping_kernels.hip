@@ -903,9 +903,8 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
   const MapEdgeRec* E = a.edges + (long long)b * a.R * 120;
   const MapNormRec* P = a.norms + (long long)b * a.cap;
   int ne = 0, np = 0;
-  for (int i = tid; i < ms.n_stack[0]; i += kMapSolveThreads) {
-    const MapEdgeRec e = E[i];
-    if (!e.valid) continue;
+  // records are fetched a few at a time ahead of the f64 work (same per-thread order as a plain strided loop)
+  auto edge_term = [&](const MapEdgeRec& e) {
     ++ne;
     double rcp[3];
     quat_rotate(q, e.cp[0], e.cp[1], e.cp[2], rcp);
@@ -933,10 +932,17 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
         add_row(acc, J, rr[row], rho1);
       }
     }
+  };
+  constexpr int U = 4;
+  const int n0 = ms.n_stack[0], n1 = ms.n_stack[1];
+  for (int i0 = tid; i0 < n0; i0 += U * kMapSolveThreads) {
+    MapEdgeRec e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * kMapSolveThreads; e[u] = E[i < n0 ? i : i0]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i0 + u * kMapSolveThreads < n0 && e[u].valid) edge_term(e[u]);
   }
-  for (int i = tid; i < ms.n_stack[1]; i += kMapSolveThreads) {
-    const MapNormRec p = P[i];
-    if (!p.valid) continue;
+  auto norm_term = [&](const MapNormRec& p) {
     ++np;
     double rcp[3];
     quat_rotate(q, p.cp[0], p.cp[1], p.cp[2], rcp);
@@ -950,6 +956,13 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
                            p.n[0], p.n[1], p.n[2]};
       add_row(acc, J, r, rho1);
     }
+  };
+  for (int i0 = tid; i0 < n1; i0 += U * kMapSolveThreads) {
+    MapNormRec pr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = i0 + u * kMapSolveThreads; pr[u] = P[i < n1 ? i : i0]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (i0 + u * kMapSolveThreads < n1 && pr[u].valid) norm_term(pr[u]);
   }
   *n_edge = ne;
   *n_norm = np;
