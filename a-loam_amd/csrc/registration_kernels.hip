@@ -354,11 +354,12 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   if (n > MAXN) { if (tid == 0) atomicOr(&a.meta[b].err, kErrRingCap); return; }
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // region A: SoA xyz tile during the curvature pass, then the curvature per point, then voxel indices + run keys (aliased)
-  constexpr int A_BYTES = (12 * MAXN > 8 * NPAD ? 12 * MAXN : 8 * NPAD);
-  float* xs = reinterpret_cast<float*>(smem);
-  float* ys = xs + MAXN;
-  float* zs = ys + MAXN;
+  // region A (aliased over time): two 266-point xyz tiles during the curvature pass, then the curvature per point, then the voxel
+  // index per element, then the run keys.  Keeping it at 8 * NPAD bytes is what lets seven workgroups share a CU's LDS.
+  constexpr int A_BYTES = 8 * NPAD;
+  constexpr int TW = 256 + 10;                                                // a chunk of 256 points + 5 on either side
+  static_assert(2 * 3 * TW * 4 <= A_BYTES && 4 * MAXN <= A_BYTES, "region A holds the curvature tiles and the curvature array");
+  float (*tile)[3][TW] = reinterpret_cast<float (*)[3][TW]>(smem);
   // all scratch lives in the dynamic region so its base stays 16-byte aligned (no static __shared__ in front)
   constexpr int FLAG_BYTES = (MAXN + 15) & ~15;
   unsigned char* flags = smem + ((A_BYTES + 15) & ~15);
@@ -372,37 +373,51 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   short* s_pick = reinterpret_cast<short*>(s_misc + 16);
 
   const float4* cloud = a.cloud + (long long)b * a.cap + start;
-  for (int i = tid; i < n; i += 256) {
-    const float4 p = cloud[i];
-    xs[i] = p.x; ys[i] = p.y; zs[i] = p.z;
-  }
-  __syncthreads();
-
-  // ---- curvature (:256-266) + gap flags, kept in registers until the tile is retired
+  // ---- curvature (:256-266) + gap flags, kept in registers until the tiles are retired.  The ring goes through LDS in chunks
+  // of 256 points (thread tid owns point it * 256 + tid = tile column tid + 5); the next chunk is fetched while this one is used.
   const int L = n - 11;                          // E - S
   float cv[ITEMS];
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 pa = tid - 5 >= 0 && tid - 5 < n ? cloud[tid - 5] : zero4, pb = tid < 10 && tid + 251 < n ? cloud[tid + 251] : zero4;
+  tile[0][0][tid] = pa.x; tile[0][1][tid] = pa.y; tile[0][2][tid] = pa.z;
+  if (tid < 10) { tile[0][0][tid + 256] = pb.x; tile[0][1][tid + 256] = pb.y; tile[0][2][tid + 256] = pb.z; }
+  __syncthreads();
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
     const int i = tid + it * 256;
+    const bool more = (it + 1) * 256 < n;                                      // uniform
+    if (more) {
+      const int ia = i + 251, ib = i + 507;                                    // columns tid and tid + 256 of the next chunk
+      pa = ia < n ? cloud[ia] : zero4;
+      pb = tid < 10 && ib < n ? cloud[ib] : zero4;
+    }
     cv[it] = 0.f;
     if (i < n) {
+      const float* xs = tile[it & 1][0] + tid + 5;
+      const float* ys = tile[it & 1][1] + tid + 5;
+      const float* zs = tile[it & 1][2] + tid + 5;
       unsigned char f = 0;
       if (i < n - 1) {
-        const float dx = xs[i + 1] - xs[i], dy = ys[i + 1] - ys[i], dz = zs[i + 1] - zs[i];
+        const float dx = xs[1] - xs[0], dy = ys[1] - ys[0], dz = zs[1] - zs[0];
         if ((double)(dx * dx + dy * dy + dz * dz) > 0.05) f = 2;              // :324 etc.
       }
       if (i >= 5 && i < n - 5) {
-        const float dX = xs[i - 5] + xs[i - 4] + xs[i - 3] + xs[i - 2] + xs[i - 1] - 10 * xs[i] + xs[i + 1] + xs[i + 2] + xs[i + 3] + xs[i + 4] + xs[i + 5];
-        const float dY = ys[i - 5] + ys[i - 4] + ys[i - 3] + ys[i - 2] + ys[i - 1] - 10 * ys[i] + ys[i + 1] + ys[i + 2] + ys[i + 3] + ys[i + 4] + ys[i + 5];
-        const float dZ = zs[i - 5] + zs[i - 4] + zs[i - 3] + zs[i - 2] + zs[i - 1] - 10 * zs[i] + zs[i + 1] + zs[i + 2] + zs[i + 3] + zs[i + 4] + zs[i + 5];
+        const float dX = xs[-5] + xs[-4] + xs[-3] + xs[-2] + xs[-1] - 10 * xs[0] + xs[1] + xs[2] + xs[3] + xs[4] + xs[5];
+        const float dY = ys[-5] + ys[-4] + ys[-3] + ys[-2] + ys[-1] - 10 * ys[0] + ys[1] + ys[2] + ys[3] + ys[4] + ys[5];
+        const float dZ = zs[-5] + zs[-4] + zs[-3] + zs[-2] + zs[-1] - 10 * zs[0] + zs[1] + zs[2] + zs[3] + zs[4] + zs[5];
         cv[it] = dX * dX + dY * dY + dZ * dZ;
         a.curv[(long long)b * a.cap + start + i] = cv[it];
       }
       flags[i] = f;
       label[i] = 0;
     }
+    if (more) {
+      const int nb = (it + 1) & 1;
+      tile[nb][0][tid] = pa.x; tile[nb][1][tid] = pa.y; tile[nb][2][tid] = pa.z;
+      if (tid < 10) { tile[nb][0][tid + 256] = pb.x; tile[nb][1][tid + 256] = pb.y; tile[nb][2][tid + 256] = pb.z; }
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   // reach of the neighbour suppression around every point: a pick of i marks i+1 .. i+fw and i-1 .. i-bk (runs of consecutive
   // gap-free steps, at most 5).  Packed into the flag byte: bit1 gap, bits 2-4 fw, bits 5-7 bk.
@@ -524,8 +539,8 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // same-voxel members, keyed (voxel index, first element), typically a third of the points.  Runs of one voxel end up adjacent
   // and in ascending element order, i.e. the members of a voxel are still summed in input order.
   unsigned* vis = reinterpret_cast<unsigned*>(smem);                          // region A: voxel index per element [NPAD] ...
-  unsigned long long* rkeys = reinterpret_cast<unsigned long long*>(smem + 4 * NPAD);   // ... and the run keys [NPAD]
-  static_assert(4 * NPAD + 8 * NPAD <= A_BYTES, "region A holds the voxel indices and the run keys");
+  unsigned long long* rkeys = reinterpret_cast<unsigned long long*>(smem);    // ... replaced by the run keys [NPAD] once the heads are known
+  static_assert(8 * NPAD <= A_BYTES, "region A holds the voxel indices, then the run keys");
   for (int e = tid; e < L; e += 256) {
     const int i = e + 5;
     unsigned vi = 0xffffffffu;                                                // not a member (corner-labelled)
@@ -548,11 +563,19 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int EIT = NPAD / 256;
   unsigned hmask = 0;                                                        // bit it: element it * 256 + tid starts a run
   int hrank[EIT];
+  unsigned myvi[EIT];
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
     const int e = it * 256 + tid;
     bool h = false;
-    if (e < L) { const unsigned vi = vis[e]; h = label[e + 5] <= 0 && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi); }
+    myvi[it] = 0xffffffffu;
+    if (e < L) {
+      const unsigned vi = vis[e];
+      const bool member = label[e + 5] <= 0;
+      h = member && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi);
+      myvi[it] = vi;
+      flags[e + 5] = (unsigned char)(member && !h);                          // the element continues the run of its predecessor
+    }
     const unsigned long long m = __ballot(h);
     hrank[it] = __popcll(m & ((1ull << lane) - 1ull));
     if (h) hmask |= 1u << it;
@@ -575,7 +598,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   }
 #pragma unroll
   for (int it = 0; it < EIT; ++it)
-    if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = ((unsigned long long)vis[e] << 32) | (unsigned long long)e; }
+    if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = ((unsigned long long)myvi[it] << 32) | (unsigned long long)e; }   // vis is dead: every thread read its share before the barrier
   const int rpad = pow2ceil(n_runs > 1 ? n_runs : 1);
   for (int q = n_runs + tid; q < rpad; q += 256) rkeys[q] = ~0ull;
   __syncthreads();
@@ -625,7 +648,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
         sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
         ++cnt;
         ++e;
-      } while (e < L && vis[e] == vi);                                        // a non-member carries 0xffffffff: the run stops there
+      } while (e < L && flags[e + 5]);                                        // the run stops at the next head or non-member
     }
     const float fc = (float)cnt;
     out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
@@ -683,7 +706,7 @@ __global__ __launch_bounds__(256) void k_compact_features(RegArgs a) {
 // -------------------------------------------------------------------------------------------------------
 size_t ring_features_lds_bytes(int npad) {
   const int maxn = npad + 11;
-  const int a_bytes = (12 * maxn > 8 * npad ? 12 * maxn : 8 * npad);
+  const int a_bytes = 8 * npad;
   const int flag_bytes = (maxn + 15) & ~15;
   return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 16) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
 }
