@@ -77,7 +77,7 @@ def lib():
             import torch  # noqa: F401
         except ImportError:
             pass
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(os.environ.get("ALOAM_MI355X_LIB", LIB_PATH))   # override: A/B runs of two builds of the same library
         vp, ip = C.c_void_p, C.POINTER(C.c_int)
         L.aloam_default_config.argtypes = [C.POINTER(AloamConfig)]; L.aloam_default_config.restype = None
         L.aloam_create.argtypes = [C.POINTER(AloamConfig), C.POINTER(vp)]
