@@ -782,27 +782,36 @@ __global__ __launch_bounds__(256) void k_map_search(MapArgs a) {
     // the reference discards the 5-NN result unless the 5th neighbour is closer than 1 m (:582, :650): collecting every point
     // with d < 1 from the 2x2x2 block and keeping the five smallest (distance, index) is an exact stand-in
     int s0[8], s1[8];
+    unsigned hh[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {                                            // the 8 bucket heads first: independent loads
-      const unsigned h = hash_cell((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz) & (unsigned)(H - 1);
-      s0[c] = start[h]; s1[c] = start[h + 1];
+      hh[c] = hash_cell((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz) & (unsigned)(H - 1);
+      s0[c] = start[hh[c]]; s1[c] = start[hh[c] + 1];
     }
+    // Two of the eight cells may share a bucket: it is walked once.  Other cells hashed into a bucket need no test of their own:
+    // every point closer than 1 m lies in one of the eight cells, so a foreign point always fails d < 1.
+#pragma unroll
+    for (int c = 1; c < 8; ++c) {
+      bool dup = false;
+#pragma unroll
+      for (int e = 0; e < c; ++e) dup = dup || hh[e] == hh[c];
+      if (dup) s1[c] = s0[c];
+    }
+    auto visit = [&](const float4& p) {
+      const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
+      const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;                   // FLANN L2_Simple, f32
+      if (d < 1.0f) top.insert(d, __float_as_int(p.w), p.x, p.y, p.z);
+    };
+    constexpr int U = 4;                                                     // independent loads in flight per lane
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int ex = (c & 1) ? nx : cx, ey = (c & 2) ? ny : cy, ez = (c & 4) ? nz : cz;
-      auto visit = [&](const float4& p) {
-        if ((int)floorf(p.x * kMapCellInv) != ex || (int)floorf(p.y * kMapCellInv) != ey || (int)floorf(p.z * kMapCellInv) != ez) return;   // another cell hashed into this bucket
-        const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
-        const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;               // FLANN L2_Simple, f32
-        if (d < 1.0f) top.insert(d, __float_as_int(p.w), p.x, p.y, p.z);
-      };
-      for (int k = s0[c]; k < s1[c]; k += 4) {                               // four independent loads in flight
+      for (int k = s0[c]; k < s1[c]; k += U) {
         const int m = s1[c] - k;
-        const float4 p0 = sorted[k], p1 = sorted[m > 1 ? k + 1 : k], p2 = sorted[m > 2 ? k + 2 : k], p3 = sorted[m > 3 ? k + 3 : k];
-        visit(p0);
-        if (m > 1) visit(p1);
-        if (m > 2) visit(p2);
-        if (m > 3) visit(p3);
+        float4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = sorted[u < m ? k + u : k];
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (u < m) visit(p[u]);
       }
     }
     float4* out = a.knn + ((long long)b * a.cap + i) * 4;
