@@ -50,8 +50,8 @@ struct aloam_ctx {
   OdomState* d_state = nullptr;
   float4* d_grid_sorted3[2] = {nullptr, nullptr}; float4* d_grid_sorted2[2] = {nullptr, nullptr};
   int* d_grid_start3[2] = {nullptr, nullptr}; int* d_grid_start2[2] = {nullptr, nullptr};
-  float4* d_grid_sorted3c[2] = {nullptr, nullptr}; float4* d_grid_sorted2c[2] = {nullptr, nullptr};   // coarse levels
-  int* d_grid_start3c[2] = {nullptr, nullptr}; int* d_grid_start2c[2] = {nullptr, nullptr};
+  float4* d_grid_sorted3c[2] = {nullptr, nullptr};   // coarse level of the 3-D grid
+  int* d_grid_start3c[2] = {nullptr, nullptr};
   int* d_grid_flags[2] = {nullptr, nullptr};
   int grid_H[2] = {4096, 16384};
   bool grids_valid = false;          // the grids describe the current "last" clouds
@@ -145,8 +145,7 @@ OdomArgs odom_args(aloam_ctx* c) {
   a.corner_last = c->d_less_sharp[1 - c->cur]; a.surf_last = c->d_less_flat[1 - c->cur];
   for (int k = 0; k < 2; ++k) {
     a.grid_sorted3[k] = c->d_grid_sorted3[k]; a.grid_sorted2[k] = c->d_grid_sorted2[k]; a.grid_start3[k] = c->d_grid_start3[k];
-    a.grid_sorted3c[k] = c->d_grid_sorted3c[k]; a.grid_sorted2c[k] = c->d_grid_sorted2c[k]; a.grid_start3c[k] = c->d_grid_start3c[k];
-    a.grid_start2c[k] = c->d_grid_start2c[k];
+    a.grid_sorted3c[k] = c->d_grid_sorted3c[k]; a.grid_start3c[k] = c->d_grid_start3c[k];
     a.grid_start2[k] = c->d_grid_start2[k];
     a.grid_flags[k] = c->d_grid_flags[k];
   }
@@ -263,9 +262,7 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
     if ((rc = dmalloc(c, &c->d_grid_start3[k], B * (c->grid_H[k] + 1)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_start2[k], B * (c->grid_H[k] + 1)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_sorted3c[k], B * per))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_sorted2c[k], B * per))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_start3c[k], B * (c->grid_H[k] + 1)))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_start2c[k], B * (c->grid_H[k] + 1)))) return rc;
     if ((rc = dmalloc(c, &c->d_grid_flags[k], B * 4))) return rc;
   }
   if ((rc = dmalloc(c, &c->d_edges, B * R * 12))) return rc;
@@ -289,8 +286,8 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
                   c->d_grid_start2[0], c->d_grid_start2[1],
-                  c->d_grid_flags[0], c->d_grid_flags[1], c->d_grid_sorted3c[0], c->d_grid_sorted3c[1], c->d_grid_sorted2c[0], c->d_grid_sorted2c[1],
-                  c->d_grid_start3c[0], c->d_grid_start3c[1], c->d_grid_start2c[0], c->d_grid_start2c[1],
+                  c->d_grid_flags[0], c->d_grid_flags[1], c->d_grid_sorted3c[0], c->d_grid_sorted3c[1],
+                  c->d_grid_start3c[0], c->d_grid_start3c[1],
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
                   c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
@@ -596,7 +593,7 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
         case K_SCATTER: bytes += 21 * Nin + 16 * N; break;
         case K_RING_FEATURES: bytes += 16 * N + 5 * N + 16 * Ls; break;
         case K_COMPACT: bytes += 32 * (Fc + Lc + Fs) + 32 * Ls; break;
-        case K_BUILD_GRIDS: bytes += 16 * (Lcl + Lsl) + 32 * (Lcl + Lsl) + 8.0 * (c->grid_H[0] + c->grid_H[1]); break;
+        case K_BUILD_GRIDS: bytes += 16 * (Lcl + Lsl) + 48 * (Lcl + Lsl) + 12.0 * (c->grid_H[0] + c->grid_H[1]); break;   // read once, three sorted copies + three bucket tables out
         case K_ASSOC_CORNER: bytes += 16 * (Fc + Lcl) + 48 * Fc; break;
         case K_ASSOC_PLANE: bytes += 16 * (Fs + Lsl) + 64 * Fs; break;
         case K_SOLVE: bytes += 9.0 * (48 * Fc + 64 * Fs); break;

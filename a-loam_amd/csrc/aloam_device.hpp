@@ -89,9 +89,7 @@ struct OdomArgs {
   int* grid_start3[2];       // [B][H+1]
   int* grid_start2[2];       // [B][H+1]
   float4* grid_sorted3c[2];  // coarse levels of the same two grids: they bound the search of far queries
-  float4* grid_sorted2c[2];
   int* grid_start3c[2];      // [B][H+1]
-  int* grid_start2c[2];      // [B][H+1]
   int* grid_flags[2];        // [B][4]   flags[0] != 0: keys / coordinates out of range -> literal brute-force path; flags[1] != 0: not ring-sorted -> literal walks
   int grid_H_corner, grid_H_surf;   // buckets (power of two, multiple of 1024)
   EdgeRec* edges;            // [B][R*12]
@@ -103,8 +101,8 @@ struct OdomArgs {
 
 struct GridView {
   int H;
-  float4 *sorted3, *sorted2, *sorted3c, *sorted2c;
-  int *start3, *start2, *start3c, *start2c, *flags;
+  float4 *sorted3, *sorted2, *sorted3c;
+  int *start3, *start2, *start3c, *flags;
 };
 __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int which) {
   GridView g;
@@ -115,9 +113,7 @@ __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int whic
   g.start3 = a.grid_start3[which] + (long long)b * (g.H + 1);
   g.start2 = a.grid_start2[which] + (long long)b * (g.H + 1);
   g.sorted3c = a.grid_sorted3c[which] + b * per;
-  g.sorted2c = a.grid_sorted2c[which] + b * per;
   g.start3c = a.grid_start3c[which] + (long long)b * (g.H + 1);
-  g.start2c = a.grid_start2c[which] + (long long)b * (g.H + 1);
   g.flags = a.grid_flags[which] + b * 4;
   return g;
 }
