@@ -191,45 +191,51 @@ __device__ __forceinline__ void shell3d(int r, int c, int* dx, int* dy, int* dz)
 // Position i belongs to the last lane whose exclusive prefix is <= i: the owners drop their lane id at their first position
 // in a 64-entry LDS row of the wave and an inclusive max-scan spreads it (prefix and spread run on the DPP network; the only
 // LDS round trips per 64 candidates are that row and the two bpermutes that fetch the owner's bucket).
-// What a lane still holds of a sweep that needed a single round (<= 128 candidates): the caller can look at the same
-// candidates again under another criterion without touching memory.
-struct Kept { float4 p0, p1; bool ok, a0, a1; };
+// What a lane still holds of a sweep that needed a single round (<= kSweep * 64 candidates): the caller can look at the
+// same candidates again under another criterion without touching memory.
+// kSweep = independent 16-B loads in flight per lane: 3 for the planar class (its fine blocks often hold 130-190 candidates),
+// 2 for the corner class (measured: a third row only costs there).
+template <int kSweep> struct Kept { float4 p[kSweep]; bool a[kSweep]; bool ok; };
 
-template <class F>
-__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f, Kept* keep = nullptr) {
+template <int kSweep, class F>
+__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f, Kept<kSweep>* keep = nullptr) {
   const int incl = wave_scan_i32<false>(cnt);
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
   int carry = 0;                                                           // owner + 1 of the position before `base`
-  for (int base = 0; base < total; base += 128) {                          // two independent loads in flight per lane
+  for (int base = 0; base < total; base += kSweep * 64) {
     const int slot = excl - base;
-    const bool two = base + 64 < total;
-    row[lane] = 0;
-    if (two) row[64 + lane] = 0;
+    const int rows = total - base > (kSweep - 1) * 64 ? kSweep : (total - base + 63) >> 6;   // uniform: rows in use this round
+#pragma unroll
+    for (int u = 0; u < kSweep; ++u) if (u < rows) row[u * 64 + lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    if (cnt > 0 && slot >= 0 && slot < (two ? 128 : 64)) row[slot] = lane + 1;
+    if (cnt > 0 && slot >= 0 && slot < rows * 64) row[slot] = lane + 1;
     __builtin_amdgcn_wave_barrier();
-    int own0 = row[lane], own1 = two ? row[64 + lane] : 0;
+    int own[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; ++u) own[u] = u < rows ? row[u * 64 + lane] : 0;
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0 && carry > own0) own0 = carry;
-    own0 = wave_scan_i32<true>(own0);
-    carry = __builtin_amdgcn_readlane(own0, 63);
-    const int i0 = base + lane, i1 = i0 + 64;
-    const int os0 = __shfl(s0, own0 - 1, 64), oe0 = __shfl(excl, own0 - 1, 64);
-    const float4 p0 = sorted[i0 < total ? os0 + (i0 - oe0) : 0];
-    if (keep) { keep->p0 = p0; keep->a0 = i0 < total; keep->a1 = false; }
-    if (two) {
-      if (lane == 0 && carry > own1) own1 = carry;
-      own1 = wave_scan_i32<true>(own1);
-      carry = __builtin_amdgcn_readlane(own1, 63);
-      const int os1 = __shfl(s0, own1 - 1, 64), oe1 = __shfl(excl, own1 - 1, 64);
-      const float4 p1 = sorted[i1 < total ? os1 + (i1 - oe1) : 0];
-      if (keep) { keep->p1 = p1; keep->a1 = i1 < total; }
-      if (i0 < total) f(p0);
-      if (i1 < total) f(p1);
-    } else if (i0 < total) f(p0);
+    float4 p[kSweep];
+#pragma unroll
+    for (int u = 0; u < kSweep; ++u) {
+      p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < rows) {
+        if (lane == 0 && carry > own[u]) own[u] = carry;
+        own[u] = wave_scan_i32<true>(own[u]);
+        carry = __builtin_amdgcn_readlane(own[u], 63);
+        const int i = base + u * 64 + lane;
+        const int os = __shfl(s0, own[u] - 1, 64), oe = __shfl(excl, own[u] - 1, 64);
+        p[u] = sorted[i < total ? os + (i - oe) : 0];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSweep; ++u) {
+      const bool act = u < rows && base + u * 64 + lane < total;
+      if (keep) { keep->p[u] = p[u]; keep->a[u] = act; }
+      if (act) f(p[u]);
+    }
   }
-  if (keep) keep->ok = total <= 128;
+  if (keep) keep->ok = total <= kSweep * 64;
 }
 
 // Distance from coordinate s to the cell [c * cell, (c + 1) * cell) along one axis (0 inside).  Points are
@@ -254,7 +260,8 @@ __device__ __forceinline__ void track_take(Track& t, bool ok, unsigned long long
 // Returns packed (f32 distance bits << 32 | index << 12 | ring key + 1), ~0 if nothing was found; `mine` is this lane's
 // share.  Distances >= 25 are not needed by the caller (DISTANCE_SQ_THRESHOLD), so the grid search stops once every
 // unvisited point is provably >= 5 m away.
-__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool bad, int which, const float4* pts, int n, const float4& sel, int lane, int* row, Track& mine, Kept& kept) {
+template <int kSweep>
+__device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool bad, int which, const float4* pts, int n, const float4& sel, int lane, int* row, Track& mine, Kept<kSweep>& kept) {
   unsigned long long best = ~0ull;
   auto visit = [&](const float4& p) {
     const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
@@ -273,7 +280,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
         s0 = g.start3[h];
         cnt = g.start3[h + 1] - s0;
       }
-      wave_sweep(g.sorted3, s0, cnt, lane, row, visit, &kept);
+      wave_sweep<kSweep>(g.sorted3, s0, cnt, lane, row, visit, &kept);
       best = wave_min_u64(mine.v);
       const float bound = (1.0f - 0.01f) * cell;                       // every unvisited point is farther than `bound`
       if (best != ~0ull && __uint_as_float((unsigned)(best >> 32)) <= bound * bound) return best;
@@ -299,7 +306,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
             cnt = g.start3c[h + 1] - s0;
           }
         }
-        wave_sweep(g.sorted3c, s0, cnt, lane, row, visit);
+        wave_sweep<kSweep>(g.sorted3c, s0, cnt, lane, row, visit);
       }
       best = wave_min_u64(mine.v);
       const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
@@ -336,7 +343,8 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, slot = L >> 3;
   const int b = (slot / (int)gridDim.x) * 8 + xcd, lane = threadIdx.x & 63;
   if (b >= a.B) return;
-  __shared__ int s_row[4][128];
+  constexpr int kSweep = PLANE ? 3 : 2;
+  __shared__ int s_row[4][kSweep * 64];
   int* row = s_row[threadIdx.x >> 6];
   const int qi = (slot % (int)gridDim.x) * 4 + (threadIdx.x >> 6);
   const int qcap = PLANE ? a.R * 24 : a.R * 12;
@@ -352,9 +360,10 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   const float4* T = PLANE ? a.surf_last + (long long)b * a.cap : a.corner_last + (long long)b * a.R * 120;
   int valid = 0;
   Track t1 = {~0ull, 0.f, 0.f, 0.f}, t2 = t1, t3 = t1;
-  Kept kept;
-  kept.ok = kept.a0 = kept.a1 = false;
-  kept.p0 = kept.p1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  Kept<kSweep> kept;
+  kept.ok = false;
+#pragma unroll
+  for (int u = 0; u < kSweep; ++u) { kept.a[u] = false; kept.p[u] = make_float4(0.f, 0.f, 0.f, 0.f); }
   unsigned long long best2 = ~0ull, best3 = ~0ull;
   const unsigned long long nn = nt > 0 ? wave_nn(g, bad, PLANE ? 1 : 0, T, nt, sel, lane, row, t1, kept) : ~0ull;
   const float nnd = __uint_as_float((unsigned)(nn >> 32));
@@ -390,8 +399,8 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
       if (kept.ok) {
         // The candidates of the fine 1-NN block are still in registers: every point within (almost) one cell of the query is
         // among them, so neighbours found there within that radius are final and the ring grid is not needed for them.
-        if (kept.a0) visit(kept.p0);
-        if (kept.a1) visit(kept.p1);
+#pragma unroll
+        for (int u = 0; u < kSweep; ++u) if (kept.a[u]) visit(kept.p[u]);
         best2 = wave_min_u64(t2.v);
         if (PLANE) best3 = wave_min_u64(t3.v);
         const float bound = (1.0f - 0.01f) * cell3_of(PLANE ? 1 : 0), b2 = bound * bound;
@@ -424,7 +433,7 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
               cnt = g.start2[h + 1] - s0;
             }
           }
-          wave_sweep(g.sorted2, s0, cnt, lane, row, visit);
+          wave_sweep<kSweep>(g.sorted2, s0, cnt, lane, row, visit);
         }
         best2 = wave_min_u64(t2.v);
         if (PLANE) best3 = wave_min_u64(t3.v);
