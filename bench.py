@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="independent sequences per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="independent sequences per GPU")
     ap.add_argument("--frames", type=int, default=6, help="stored sweeps per sequence (replayed ping-pong)")
     ap.add_argument("--sensor", default="HDL-64")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
