@@ -40,6 +40,7 @@ void orc_default_config(orc_config* cfg) {
   cfg->apply_converged_step = 0;
   cfg->lm_max_iterations = 4;
   cfg->outer_iterations = 2;
+  cfg->distortion = 0;
 }
 
 orc_ctx* orc_create(const orc_config* cfg) {
@@ -178,6 +179,11 @@ static std::vector<orc::PlaneRec> planes_from(const double* e, int n) {
 int orc_factor_eval(int kind, const double* consts, const double q[4], const double t[3], int analytic, double* r, double* J) {
   if (kind == 0) { orc::factor_eval_edge(edges_from(consts, 1)[0], q, t, analytic != 0, r, J); return 3; }
   if (kind == 1) { orc::factor_eval_plane(planes_from(consts, 1)[0], q, t, analytic != 0, r, J); return 1; }
+  return -1;
+}
+int orc_factor_eval_s(int kind, const double* consts, double s, const double q[4], const double t[3], double* r, double* J) {
+  if (kind == 0) { orc::EdgeRec e = edges_from(consts, 1)[0]; e.s = s; orc::factor_eval_edge(e, q, t, false, r, J); return 3; }
+  if (kind == 1) { orc::PlaneRec p = planes_from(consts, 1)[0]; p.s = s; orc::factor_eval_plane(p, q, t, false, r, J); return 1; }
   return -1;
 }
 double orc_cost(int n_edges, const double* edges, int n_planes, const double* planes, const double q[4], const double t[3]) {

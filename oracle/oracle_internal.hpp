@@ -35,8 +35,8 @@ struct NnIndex {
   void search(int node, const float q[3], int* best, float* bestd) const;
 };
 
-struct EdgeRec { V3d cp, a, b; int query; };          // LidarEdgeFactor ctor args  (lidarFactor.hpp:14-16)
-struct PlaneRec { V3d cp, j, l, m; int query; };       // LidarPlaneFactor ctor args (lidarFactor.hpp:59-62)
+struct EdgeRec { V3d cp, a, b; int query; double s = 1.0; };          // LidarEdgeFactor ctor args  (lidarFactor.hpp:14-16); s: interpolation ratio
+struct PlaneRec { V3d cp, j, l, m; int query; double s = 1.0; };       // LidarPlaneFactor ctor args (lidarFactor.hpp:59-62)
 
 struct NormRec { V3d cp, n; double d; int query; };   // LidarPlaneNormFactor ctor args (lidarFactor.hpp:109-111)
 

@@ -94,10 +94,15 @@ void NnIndex::query(const P4& qp, bool brute, int* idx, float* d2) const {
 }
 
 // ---------------------------------------------------------------------------------------------
-// TransformToStart (:111-129) with DISTORTION 0 -> s = 1.
+// TransformToStart (:111-129): s = 1 with DISTORTION 0 (:59), else the point's relative time / SCAN_PERIOD (:115-116, f32
+// difference divided by the double 0.1).
 // ---------------------------------------------------------------------------------------------
-static P4 transform_to_start(const P4& pi, const double para_q[4], const double para_t[3]) {
-  const double s = 1.0;
+static double interpolation_ratio(const P4& pi, int distortion) {
+  const double SCAN_PERIOD = 0.1;            // :64
+  return distortion ? (pi.i - int(pi.i)) / SCAN_PERIOD : 1.0;
+}
+static P4 transform_to_start(const P4& pi, const double para_q[4], const double para_t[3], int distortion) {
+  const double s = interpolation_ratio(pi, distortion);
   const Quatd q_last_curr{para_q[0], para_q[1], para_q[2], para_q[3]};
   const Quatd q_point_last = slerp_from_identity(s, q_last_curr);
   const V3d t_point_last{s * para_t[0], s * para_t[1], s * para_t[2]};
@@ -126,7 +131,7 @@ int odometry_step(const orc_config& cfg, const std::vector<P4>& sharp, const std
       st->planes.clear();
       // ---- corners (:299-384)
       for (int i = 0; i < (int)sharp.size() && !CL.empty(); ++i) {
-        const P4 sel = transform_to_start(sharp[i], st->para_q, st->para_t);
+        const P4 sel = transform_to_start(sharp[i], st->para_q, st->para_t, cfg.distortion);
         int nn; float nnd;
         st->tree_corner.query(sel, cfg.nn_brute != 0, &nn, &nnd);
         int closest = -1, min2 = -1;
@@ -153,12 +158,13 @@ int odometry_step(const orc_config& cfg, const std::vector<P4>& sharp, const std
           e.a = V3d{CL[closest].x, CL[closest].y, CL[closest].z};
           e.b = V3d{CL[min2].x, CL[min2].y, CL[min2].z};
           e.query = i;
+          e.s = interpolation_ratio(sharp[i], cfg.distortion);      // :376-377
           st->edges.push_back(e);
         }
       }
       // ---- planes (:387-483)
       for (int i = 0; i < (int)flat.size() && !SL.empty(); ++i) {
-        const P4 sel = transform_to_start(flat[i], st->para_q, st->para_t);
+        const P4 sel = transform_to_start(flat[i], st->para_q, st->para_t, cfg.distortion);
         int nn; float nnd;
         st->tree_surf.query(sel, cfg.nn_brute != 0, &nn, &nnd);
         int closest = -1, min2 = -1, min3 = -1;
@@ -185,6 +191,7 @@ int odometry_step(const orc_config& cfg, const std::vector<P4>& sharp, const std
             p.l = V3d{SL[min2].x, SL[min2].y, SL[min2].z};
             p.m = V3d{SL[min3].x, SL[min3].y, SL[min3].z};
             p.query = i;
+            p.s = interpolation_ratio(flat[i], cfg.distortion);     // :474-475
             st->planes.push_back(p);
           }
         }

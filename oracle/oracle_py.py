@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "build", "liboracle.so")
 class OrcConfig(C.Structure):
     _fields_ = [("n_scans", C.c_int), ("min_range", C.c_float), ("ring_from_field", C.c_int), ("canonical_order", C.c_int),
                 ("nn_brute", C.c_int), ("analytic_jacobian", C.c_int), ("apply_converged_step", C.c_int),
-                ("lm_max_iterations", C.c_int), ("outer_iterations", C.c_int)]
+                ("lm_max_iterations", C.c_int), ("outer_iterations", C.c_int), ("distortion", C.c_int)]
 
 
 class OrcOdomStats(C.Structure):
@@ -69,6 +69,7 @@ def lib():
         L.orc_voxel_filter.argtypes = [vp, C.c_int, C.c_float, C.c_int, vp, C.c_int]
         L.orc_nn_search.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
         L.orc_factor_eval.argtypes = [C.c_int, vp, vp, vp, C.c_int, vp, vp]
+        L.orc_factor_eval_s.argtypes = [C.c_int, vp, C.c_double, vp, vp, vp, vp]
         L.orc_cost.argtypes = [C.c_int, vp, C.c_int, vp, vp, vp]; L.orc_cost.restype = C.c_double
         L.orc_lm_solve.argtypes = [C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, ip]
         L.orc_atan2f_port.argtypes = [C.c_float, C.c_float]; L.orc_atan2f_port.restype = C.c_float
@@ -103,13 +104,14 @@ class Oracle:
     """One sequence: scan registration + odometry state, mirroring the two reference nodes."""
 
     def __init__(self, n_scans=64, min_range=5.0, ring_from_field=False, canonical_order=True, nn_brute=False,
-                 analytic_jacobian=False, apply_converged_step=False, lm_max_iterations=4, outer_iterations=2):
+                 analytic_jacobian=False, apply_converged_step=False, lm_max_iterations=4, outer_iterations=2, distortion=False):
         L = lib()
         cfg = OrcConfig()
         L.orc_default_config(C.byref(cfg))
         cfg.n_scans, cfg.min_range, cfg.ring_from_field = n_scans, min_range, int(ring_from_field)
         cfg.canonical_order, cfg.nn_brute, cfg.analytic_jacobian = int(canonical_order), int(nn_brute), int(analytic_jacobian)
         cfg.apply_converged_step, cfg.lm_max_iterations, cfg.outer_iterations = int(apply_converged_step), lm_max_iterations, outer_iterations
+        cfg.distortion = int(distortion)
         self.cfg = cfg
         self.n_scans = n_scans
         self.h = L.orc_create(C.byref(cfg))
@@ -272,6 +274,15 @@ def factor_eval(kind, consts, q, t, analytic):
     rows = 3 if kind == 0 else 1
     r = np.zeros(rows); J = np.zeros((rows, 6))
     lib().orc_factor_eval(kind, _p(c), _p(q), _p(t), int(analytic), _p(r), _p(J))
+    return r, J
+
+
+def factor_eval_s(kind, consts, s, q, t):
+    """Residual + Jacobian (projected through the quaternion Plus Jacobian) of one factor with interpolation ratio s."""
+    c, q, t = _f64(consts), _f64(q), _f64(t)
+    rows = 3 if kind == 0 else 1
+    r = np.zeros(rows); J = np.zeros((rows, 6))
+    lib().orc_factor_eval_s(kind, _p(c), float(s), _p(q), _p(t), _p(r), _p(J))
     return r, J
 
 

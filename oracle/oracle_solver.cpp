@@ -17,11 +17,12 @@ namespace orc {
 
 // ---------------------------------------------------------------------------------------------
 // Functors, templated on the scalar exactly like the reference's operator() so that the Jet
-// instantiation reproduces what ceres::AutoDiffCostFunction differentiates (s = 1, DISTORTION 0).
+// instantiation reproduces what ceres::AutoDiffCostFunction differentiates.  s is the interpolation ratio the reference
+// passes to the constructors: 1 with DISTORTION 0 (reference src/laserOdometry.cpp:59), the point's relative time otherwise.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 static void edge_functor(const EdgeRec& e, const T* q, const T* t, T* residual) {
-  const double s = 1.0;
+  const double s = e.s;
   const V3<T> cp{T(e.cp.x), T(e.cp.y), T(e.cp.z)};
   const V3<T> lpa{T(e.a.x), T(e.a.y), T(e.a.z)};
   const V3<T> lpb{T(e.b.x), T(e.b.y), T(e.b.z)};
@@ -44,7 +45,7 @@ static V3d plane_normal(const PlaneRec& p) {       // LidarPlaneFactor ctor (lid
 
 template <typename T>
 static void plane_functor(const PlaneRec& p, const V3d& ljm_norm, const T* q, const T* t, T* residual) {
-  const double s = 1.0;
+  const double s = p.s;
   const V3<T> cp{T(p.cp.x), T(p.cp.y), T(p.cp.z)};
   const V3<T> lpj{T(p.j.x), T(p.j.y), T(p.j.z)};
   const V3<T> ljm{T(ljm_norm.x), T(ljm_norm.y), T(ljm_norm.z)};
@@ -81,7 +82,7 @@ static void closed_form_lp(const V3d& cp, const double q[4], const double t[3], 
 }
 
 void factor_eval_edge(const EdgeRec& e, const double q[4], const double t[3], bool analytic, double r[3], double J[18]) {
-  if (!analytic) {
+  if (!analytic || e.s != 1.0) {                      // the closed form below is the s = 1 case
     typedef Jet<7> J7;
     J7 jq[4], jt[3], jr[3];
     for (int k = 0; k < 4; ++k) jq[k] = J7(q[k], k);
@@ -121,7 +122,7 @@ void factor_eval_edge(const EdgeRec& e, const double q[4], const double t[3], bo
 
 void factor_eval_plane(const PlaneRec& p, const double q[4], const double t[3], bool analytic, double r[1], double J[6]) {
   const V3d n = plane_normal(p);
-  if (!analytic) {
+  if (!analytic || p.s != 1.0) {
     typedef Jet<7> J7;
     J7 jq[4], jt[3], jr[1];
     for (int k = 0; k < 4; ++k) jq[k] = J7(q[k], k);

@@ -141,3 +141,17 @@ def laser_mapping(frames, line_res, plane_res, dump_map=True, exe=None, exe_args
             out.append(fr)
         assert rd.done()
         return out
+
+
+def lidar_factors(records, exe=None):
+    """records: (n, 21) float64 rows [kind, s, q(xyzw), t, 12 constants] -> residual (n,3), d r/d q (n,3,4), d r/d t (n,3,3)
+    from the reference's LidarEdgeFactor / LidarPlaneFactor through ceres::AutoDiffCostFunction (stand-in Ceres)."""
+    rec = np.ascontiguousarray(records, dtype=np.float64).reshape(-1, 21)
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<i", rec.shape[0]))
+            f.write(rec.tobytes())
+        subprocess.run([exe or os.path.join(REF_DIR, "ref_lidar_factor"), fin, fout], check=True)
+        out = np.fromfile(fout, dtype="<f8").reshape(rec.shape[0], 24)
+    return out[:, :3].copy(), out[:, 3:15].reshape(-1, 3, 4).copy(), out[:, 15:].reshape(-1, 3, 3).copy()

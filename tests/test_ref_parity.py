@@ -225,3 +225,24 @@ def test_mapping_cube_window_shift_matches_reference_code(O):
             for cube in got:
                 assert bits_equal(got[cube], ref[k][name][cube]), (k, name, cube)
     assert shifted
+
+
+def test_oracle_functors_with_interpolation_ratio_match_reference_templates(O):
+    """The s != 1 branch of LidarEdgeFactor / LidarPlaneFactor (what DISTORTION 1 would feed them; the reference's nodes compile
+    it out): residuals and Jacobians of the reference's own templates (tests/golden/reffactor_s.npz, tools/make_ref_golden.py)
+    against the oracle's functors, the 4-column quaternion block projected through the Plus Jacobian of
+    EigenQuaternionParameterization as Ceres does."""
+    g = np.load(os.path.join(GOLDEN, "reffactor_s.npz"))
+    rec, res, jq, jt = g["records"], g["residual"], g["jac_q"], g["jac_t"]
+    worst = 0.0
+    for i in range(len(rec)):
+        kind, s, q, t, c = int(rec[i, 0]), rec[i, 1], rec[i, 2:6], rec[i, 6:9], rec[i, 9:21]
+        rows = 3 if kind == 0 else 1
+        r, J = O.factor_eval_s(kind, c[:9] if kind == 0 else c, s, q, t)
+        x, y, z, w = q
+        P = np.array([[w, z, -y], [-z, w, x], [y, -x, w], [-x, -y, -z]])
+        Jref = np.concatenate([jq[i, :rows] @ P, jt[i, :rows]], axis=1)
+        scale = max(1.0, np.abs(Jref).max())
+        assert np.array_equal(r, res[i, :rows]), (i, r, res[i, :rows])             # same operations in the same order: bit-exact
+        worst = max(worst, np.abs(J - Jref).max() / scale)
+    assert worst < 1e-12, worst

@@ -69,6 +69,28 @@ def main_mapping():
         print(path, os.path.getsize(path) // 1024, "KiB")
 
 
+def main_factors():
+    """The reference's LidarEdgeFactor / LidarPlaneFactor with a general interpolation ratio s (the branch its nodes compile out
+    with #define DISTORTION 0): residuals and per-block Jacobians from its own templates -> tests/golden/reffactor_s.npz."""
+    rng = np.random.default_rng(2024)
+    n = 400
+    rec = np.zeros((n, 21))
+    rec[:, 0] = np.arange(n) % 2
+    rec[:, 1] = np.concatenate([rng.uniform(0.0, 1.0, n - 6), [0.0, 1.0, 0.5, 1e-9, 1.0 - 1e-12, 0.25]])
+    ang = rng.uniform(0, 0.2, n); ang[:8] = [0.0, 1e-9, 1e-8, 3e-8, 1e-7, 1e-4, 3.0, 3.14]     # incl. the (1 - eps) guard of slerp and q.w < 0
+    ax = rng.normal(size=(n, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    rec[:, 2:5] = ax * np.sin(ang / 2)[:, None]; rec[:, 5] = np.cos(ang / 2)
+    rec[8:16, 2:6] *= -1.0                                                                   # d < 0 branch
+    rec[:, 6:9] = rng.normal(scale=0.5, size=(n, 3))
+    rec[:, 9:21] = rng.uniform(-30, 30, (n, 12))
+    rec[:, 12:21] = rec[:, 9:12].repeat(3, 0).reshape(n, 9) + rng.normal(scale=1.0, size=(n, 9))   # neighbours near the point
+    r, jq, jt = ref_py.lidar_factors(rec)
+    path = os.path.join(ROOT, "tests", "golden", "reffactor_s.npz")
+    np.savez_compressed(path, records=rec, residual=r, jac_q=jq, jac_t=jt)
+    print(path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     main()
     main_mapping()
+    main_factors()
