@@ -27,7 +27,7 @@ MAP_INFO_KEYS = ("cenW", "cenH", "cenD", "frame_count", "from_map_corner", "from
 class AloamConfig(C.Structure):
     _fields_ = [("n_scans", C.c_int), ("min_range", C.c_float), ("ring_from_field", C.c_int), ("batch", C.c_int),
                 ("max_points", C.c_int), ("max_ring_points", C.c_int), ("device", C.c_int), ("lm_max_iterations", C.c_int),
-                ("outer_iterations", C.c_int)]
+                ("outer_iterations", C.c_int), ("distortion", C.c_int)]
 
 
 class AloamOdomStats(C.Structure):
@@ -134,13 +134,14 @@ class Aloam:
     `gpu.scan_register(x)` next to `oracle.scan_register(x)`."""
 
     def __init__(self, n_scans=64, min_range=5.0, ring_from_field=False, batch=1, max_points=140000, max_ring_points=4107,
-                 device=0, lm_max_iterations=4, outer_iterations=2):
+                 device=0, lm_max_iterations=4, outer_iterations=2, distortion=False):
         L = lib()
         cfg = AloamConfig()
         L.aloam_default_config(C.byref(cfg))
         cfg.n_scans, cfg.min_range, cfg.ring_from_field, cfg.batch = n_scans, min_range, int(ring_from_field), batch
         cfg.max_points, cfg.max_ring_points, cfg.device = max_points, max_ring_points, device
         cfg.lm_max_iterations, cfg.outer_iterations = lm_max_iterations, outer_iterations
+        cfg.distortion = int(distortion)
         self.cfg, self.batch, self.n_scans, self.max_points = cfg, batch, n_scans, max_points
         h = C.c_void_p()
         rc = L.aloam_create(C.byref(cfg), C.byref(h))

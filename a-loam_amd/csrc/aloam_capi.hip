@@ -152,6 +152,7 @@ OdomArgs odom_args(aloam_ctx* c) {
   a.grid_H_corner = c->grid_H[0]; a.grid_H_surf = c->grid_H[1];
   a.edges = c->d_edges; a.planes = c->d_planes;
   a.lm_max_iterations = c->cfg.lm_max_iterations;
+  a.distortion = c->cfg.distortion != 0;
   return a;
 }
 
@@ -206,6 +207,7 @@ void aloam_default_config(aloam_config* cfg) {
   cfg->device = 0;
   cfg->lm_max_iterations = 4;
   cfg->outer_iterations = 2;
+  cfg->distortion = 0;
 }
 
 int aloam_create(const aloam_config* cfg, aloam_ctx** out) {

@@ -97,6 +97,7 @@ struct OdomArgs {
   int outer;                 // which outer iteration (0/1)
   int last_outer;            // 1: integrate the pose after solving (src/laserOdometry.cpp:504-505)
   int lm_max_iterations;
+  int distortion;            // 1: per-point interpolation ratio (reference DISTORTION 1); 0: s = 1
 };
 
 struct GridView {

@@ -33,6 +33,77 @@ __device__ __forceinline__ float4 transform_to_start(const float4& p, const Odom
   return make_float4((float)(o[0] + st.para_t[0]), (float)(o[1] + st.para_t[1]), (float)(o[2] + st.para_t[2]), p.w);
 }
 
+// ---- DISTORTION 1 (reference src/laserOdometry.cpp:59 ships 0) ---------------------------------------------------------
+// Interpolation ratio of a point: (intensity - int(intensity)) / SCAN_PERIOD, an f32 difference divided by the double 0.1
+// (:115-116, :376-377, :474-475).
+__device__ __forceinline__ double interpolation_ratio(float frac) { return (double)frac / 0.1; }
+
+// Identity.slerp(s, q) as Eigen's QuaternionBase::slerp evaluates it: the result is scale0 * Identity + scale1 * q (a
+// coefficient blend, not re-normalised); both scales depend on q only through d = q.w, so their derivatives do too.
+__device__ __forceinline__ void slerp_scales(double w, double s, double* c0, double* c1, double* dc0, double* dc1) {
+  const double one = 1.0 - 2.220446049250313e-16;
+  const double absD = fabs(w);
+  if (absD >= one) { *c0 = 1.0 - s; *c1 = s; *dc0 = 0.0; *dc1 = 0.0; }
+  else {
+    const double theta = acos(absD), st = sin(theta), ct = cos(theta);
+    const double a0 = (1.0 - s) * theta, a1 = s * theta;
+    *c0 = sin(a0) / st;
+    *c1 = sin(a1) / st;
+    // d/dtheta of sin(k theta) / sin(theta), then d theta / d absD = -1 / sin(theta), d absD / d w = sign(w)
+    const double g = (w < 0.0 ? 1.0 : -1.0) / st;
+    *dc0 = ((1.0 - s) * cos(a0) * st - sin(a0) * ct) / (st * st) * g;
+    *dc1 = (s * cos(a1) * st - sin(a1) * ct) / (st * st) * g;
+  }
+  if (w < 0.0) { *c1 = -*c1; *dc1 = -*dc1; }
+}
+
+// lp = slerp(I, q, s) * cp + s t (reference src/lidarFactor.hpp:27-32 / :79-84 and TransformToStart) and, if M is given, the
+// 3x4 matrix d lp / d (qx, qy, qz, qw) that forward-mode autodiff of those lines produces.
+__device__ __forceinline__ void deskew_point(const double q[4], const double t[3], double s, double vx, double vy, double vz,
+                                             double lp[3], double (*M)[4]) {
+  double c0, c1, dc0, dc1;
+  slerp_scales(q[3], s, &c0, &c1, &dc0, &dc1);
+  const double u[3] = {c1 * q[0], c1 * q[1], c1 * q[2]}, w = c0 + c1 * q[3];
+  const double v[3] = {vx, vy, vz};
+  // Eigen: uv = 2 u x v; result = v + w uv + u x uv
+  const double uv[3] = {2.0 * (u[1] * v[2] - u[2] * v[1]), 2.0 * (u[2] * v[0] - u[0] * v[2]), 2.0 * (u[0] * v[1] - u[1] * v[0])};
+  lp[0] = v[0] + w * uv[0] + (u[1] * uv[2] - u[2] * uv[1]) + s * t[0];
+  lp[1] = v[1] + w * uv[1] + (u[2] * uv[0] - u[0] * uv[2]) + s * t[1];
+  lp[2] = v[2] + w * uv[2] + (u[0] * uv[1] - u[1] * uv[0]) + s * t[2];
+  if (!M) return;
+  // d result / d u_k = 2 w (e_k x v) + e_k x uv + u x (2 e_k x v);   d result / d w = uv
+  double Du[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double e[3] = {0.0, 0.0, 0.0};
+    e[k] = 1.0;
+    const double ev[3] = {2.0 * (e[1] * v[2] - e[2] * v[1]), 2.0 * (e[2] * v[0] - e[0] * v[2]), 2.0 * (e[0] * v[1] - e[1] * v[0])};
+    Du[0][k] = w * ev[0] + (e[1] * uv[2] - e[2] * uv[1]) + (u[1] * ev[2] - u[2] * ev[1]);
+    Du[1][k] = w * ev[1] + (e[2] * uv[0] - e[0] * uv[2]) + (u[2] * ev[0] - u[0] * ev[2]);
+    Du[2][k] = w * ev[2] + (e[0] * uv[1] - e[1] * uv[0]) + (u[0] * ev[1] - u[1] * ev[0]);
+  }
+  const double dw = dc0 + dc1 * q[3] + c1;                                   // d w / d qw
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    M[r][0] = c1 * Du[r][0];
+    M[r][1] = c1 * Du[r][1];
+    M[r][2] = c1 * Du[r][2];
+    M[r][3] = dc1 * (Du[r][0] * q[0] + Du[r][1] * q[1] + Du[r][2] * q[2]) + uv[r] * dw;
+  }
+}
+
+// Row of the residual Jacobian in the tangent space Ceres solves in: (d r / d lp) (d lp / d q) Plus'(q), and d lp / d t = s I.
+__device__ __forceinline__ void deskew_jacobian_row(const double a[3], const double (*M)[4], const double q[4], double s, double J[6]) {
+  double g[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] = a[0] * M[0][j] + a[1] * M[1][j] + a[2] * M[2][j];
+  // EigenQuaternionParameterization Plus Jacobian at delta = 0 (rows x, y, z, w)
+  J[0] = g[0] * q[3] - g[1] * q[2] + g[2] * q[1] - g[3] * q[0];
+  J[1] = g[0] * q[2] + g[1] * q[3] - g[2] * q[0] - g[3] * q[1];
+  J[2] = -g[0] * q[1] + g[1] * q[0] + g[2] * q[3] - g[3] * q[2];
+  J[3] = a[0] * s; J[4] = a[1] * s; J[5] = a[2] * s;
+}
+
 // -------------------------------------------------------------------------------------------------------
 // Spatial hash grids over the "last" clouds (stand-in for pcl::KdTreeFLANN::setInputCloud, reference
 // src/laserOdometry.cpp:567-568).  Two grids per cloud, both built by one 1024-thread workgroup per (sequence, cloud)
@@ -334,7 +405,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
 // The kernel is a chain of dependent memory round trips per query (bucket bounds -> bucket entries, twice), so everything
 // that does not depend on a search result is loaded up front and nothing is fetched by index afterwards: grid entries
 // carry their ring key, and the lanes that saw the winners store the record fields themselves.
-template <bool PLANE>
+template <bool PLANE, bool DISTORT>
 __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs by linear id and every XCD has its
   // own 4 MiB L2.  The grids of one sequence (~1.5 MB) are shared by all workgroups of that sequence, so the linear id
@@ -353,7 +424,15 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   const SeqMeta m = a.meta[b];
   const GridView g = grid_view(a, b, PLANE ? 1 : 0);
   const bool bad = g.flags[0] != 0, unsorted = g.flags[1] != 0;
-  const float4 sel = transform_to_start(raw, a.state[b]);
+  const float frac = raw.w - (float)(int)raw.w;                              // relTime of the point (:116)
+  float4 sel;
+  if (DISTORT) {
+    const OdomState& st = a.state[b];
+    const double q[4] = {st.para_q[0], st.para_q[1], st.para_q[2], st.para_q[3]}, t[3] = {st.para_t[0], st.para_t[1], st.para_t[2]};
+    double lp[3];
+    deskew_point(q, t, interpolation_ratio(frac), (double)raw.x, (double)raw.y, (double)raw.z, lp, nullptr);
+    sel = make_float4((float)lp[0], (float)lp[1], (float)lp[2], raw.w);
+  } else sel = transform_to_start(raw, a.state[b]);
   const int nq = PLANE ? m.n_flat : m.n_sharp;
   if (qi >= nq) return;
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
@@ -479,7 +558,7 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
     PlaneRec* e = a.planes + (long long)b * a.R * 24 + qi;
     if (lane == 0) {
       e->cp[0] = raw.x; e->cp[1] = raw.y; e->cp[2] = raw.z;
-      e->valid = valid; e->pad[0] = e->pad[1] = e->pad[2] = 0;
+      e->valid = valid; e->pad[0] = __float_as_int(frac); e->pad[1] = e->pad[2] = 0;
       if (!valid) for (int k = 0; k < 3; ++k) e->j[k] = e->l[k] = e->m[k] = 0.f;
     }
     if (valid) {
@@ -491,7 +570,7 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
     EdgeRec* e = a.edges + (long long)b * a.R * 12 + qi;
     if (lane == 0) {
       e->cp[0] = raw.x; e->cp[1] = raw.y; e->cp[2] = raw.z;
-      e->valid = valid; e->pad[0] = e->pad[1] = 0;
+      e->valid = valid; e->pad[0] = __float_as_int(frac); e->pad[1] = 0;
       if (!valid) for (int k = 0; k < 3; ++k) e->a[k] = e->b[k] = 0.f;
     }
     if (valid) {
@@ -502,7 +581,7 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-template <bool WITH_JAC>
+template <bool WITH_JAC, bool DISTORT>
 __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const double t[3], double* acc, int* n_edge, int* n_plane) {
   const int tid = threadIdx.x;
   const SeqMeta m = a.meta[b];
@@ -513,9 +592,13 @@ __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const doub
     const EdgeRec e = E[i];
     if (!e.valid) continue;
     ++ne;
-    double rcp[3];
-    quat_rotate(q, (double)e.cp[0], (double)e.cp[1], (double)e.cp[2], rcp);
-    const double lp[3] = {rcp[0] + t[0], rcp[1] + t[1], rcp[2] + t[2]};
+    double rcp[3], lp[3], M[3][4];
+    const double s = DISTORT ? interpolation_ratio(__int_as_float(e.pad[0])) : 1.0;
+    if (DISTORT) deskew_point(q, t, s, (double)e.cp[0], (double)e.cp[1], (double)e.cp[2], lp, WITH_JAC ? M : nullptr);
+    else {
+      quat_rotate(q, (double)e.cp[0], (double)e.cp[1], (double)e.cp[2], rcp);
+      lp[0] = rcp[0] + t[0]; lp[1] = rcp[1] + t[1]; lp[2] = rcp[2] + t[2];
+    }
     const double ax = e.a[0], ay = e.a[1], az = e.a[2], bx = e.b[0], by = e.b[1], bz = e.b[2];
     const double dex = ax - bx, dey = ay - by, dez = az - bz;
     const double inv = 1.0 / sqrt(dex * dex + dey * dey + dez * dez);
@@ -533,10 +616,13 @@ __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const doub
 #pragma unroll
       for (int row = 0; row < 3; ++row) {
         double J[6];
+        if (DISTORT) deskew_jacobian_row(A[row], M, q, s, J);
+        else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          J[c] = A[row][0] * Bm[0][c] + A[row][1] * Bm[1][c] + A[row][2] * Bm[2][c];
-          J[3 + c] = A[row][c];
+          for (int c = 0; c < 3; ++c) {
+            J[c] = A[row][0] * Bm[0][c] + A[row][1] * Bm[1][c] + A[row][2] * Bm[2][c];
+            J[3 + c] = A[row][c];
+          }
         }
         add_row(acc, J, rr[row], rho1);
       }
@@ -553,14 +639,22 @@ __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const doub
     double nx = e1y * e2z - e1z * e2y, ny = e1z * e2x - e1x * e2z, nz = e1x * e2y - e1y * e2x;
     const double len = sqrt(nx * nx + ny * ny + nz * nz);
     nx /= len; ny /= len; nz /= len;
-    double rcp[3];
-    quat_rotate(q, (double)p.cp[0], (double)p.cp[1], (double)p.cp[2], rcp);
-    const double r = (rcp[0] + t[0] - jx) * nx + (rcp[1] + t[1] - jy) * ny + (rcp[2] + t[2] - jz) * nz;
+    double rcp[3] = {0.0, 0.0, 0.0}, lp[3], M[3][4];
+    const double s = DISTORT ? interpolation_ratio(__int_as_float(p.pad[0])) : 1.0;
+    if (DISTORT) deskew_point(q, t, s, (double)p.cp[0], (double)p.cp[1], (double)p.cp[2], lp, WITH_JAC ? M : nullptr);
+    else {
+      quat_rotate(q, (double)p.cp[0], (double)p.cp[1], (double)p.cp[2], rcp);
+      lp[0] = rcp[0] + t[0]; lp[1] = rcp[1] + t[1]; lp[2] = rcp[2] + t[2];
+    }
+    const double r = (lp[0] - jx) * nx + (lp[1] - jy) * ny + (lp[2] - jz) * nz;
     double rho0, rho1;
     huber(r * r, &rho0, &rho1);
     acc[27] += 0.5 * rho0;
     if (WITH_JAC) {
-      const double J[6] = {2.0 * (nz * rcp[1] - ny * rcp[2]), 2.0 * (nx * rcp[2] - nz * rcp[0]), 2.0 * (ny * rcp[0] - nx * rcp[1]), nx, ny, nz};
+      double J[6];
+      const double nn[3] = {nx, ny, nz};
+      if (DISTORT) deskew_jacobian_row(nn, M, q, s, J);
+      else { J[0] = 2.0 * (nz * rcp[1] - ny * rcp[2]); J[1] = 2.0 * (nx * rcp[2] - nz * rcp[0]); J[2] = 2.0 * (ny * rcp[0] - nx * rcp[1]); J[3] = nx; J[4] = ny; J[5] = nz; }
       add_row(acc, J, r, rho1);
     }
   }
@@ -570,6 +664,7 @@ __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const doub
 
 // One workgroup per sequence: the whole ceres::Solve stand-in + pose integration.
 // Every thread runs the (uniform) scalar LM logic redundantly; only the evaluations are distributed.
+template <bool DISTORT>
 __global__ __launch_bounds__(256) void k_solve(OdomArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
   __shared__ double s_red[4 * 28];
@@ -578,7 +673,7 @@ __global__ __launch_bounds__(256) void k_solve(OdomArgs a) {
   double t[3] = {st.para_t[0], st.para_t[1], st.para_t[2]};
 
   const LmResult lm = lm_solve_block([&](bool with_jac, const double* qq, const double* tt, double* acc, int* ne, int* np) {
-    if (with_jac) evaluate<true>(a, b, qq, tt, acc, ne, np); else evaluate<false>(a, b, qq, tt, acc, ne, np);
+    if (with_jac) evaluate<true, DISTORT>(a, b, qq, tt, acc, ne, np); else evaluate<false, DISTORT>(a, b, qq, tt, acc, ne, np);
   }, q, t, a.lm_max_iterations, s_red);
   const int n_edges = lm.n_a, n_planes = lm.n_b, iterations = lm.iterations, successful = lm.successful, termination = lm.termination;
   const double initial_cost = lm.initial_cost, cost = lm.final_cost;
@@ -627,9 +722,18 @@ void launch_build_grids(const OdomArgs& a, hipStream_t s) {
 }
 void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
-  if (plane) hipLaunchKernelGGL(k_associate<true>, dim3((max_queries + 3) / 4, by), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_associate<false>, dim3((max_queries + 3) / 4, by), dim3(256), 0, s, a);
+  const dim3 grid((max_queries + 3) / 4, by);
+  if (a.distortion) {
+    if (plane) hipLaunchKernelGGL((k_associate<true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_associate<false, true>), grid, dim3(256), 0, s, a);
+  } else {
+    if (plane) hipLaunchKernelGGL((k_associate<true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_associate<false, false>), grid, dim3(256), 0, s, a);
+  }
 }
-void launch_solve(const OdomArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_solve, dim3(a.B), dim3(256), 0, s, a); }
+void launch_solve(const OdomArgs& a, hipStream_t s) {
+  if (a.distortion) hipLaunchKernelGGL(k_solve<true>, dim3(a.B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_solve<false>, dim3(a.B), dim3(256), 0, s, a);
+}
 
 }  // namespace aloam

@@ -207,7 +207,10 @@ def main():
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
         if pm.get("batch") == B and pm.get("mapping") == bool(args.mapping) and pm.get("sensor") == args.sensor:
-            rk = {"k_associate[plane]": "k_associate<true>", "k_associate[corner]": "k_associate<false>", "k_ring_features": "k_ring_features<2048>"}.get(dname, dname)
+            rk = {"k_associate[plane]": "k_associate<true, false>", "k_associate[corner]": "k_associate<false, false>", "k_ring_features": "k_ring_features<2048>",
+                  "k_solve": "k_solve<false>"}.get(dname, dname)
+            if rk not in pm["fetch_kib"]:
+                rk = rk.replace(", false>", ">").replace("<false>", "")          # names of builds before the de-skew template parameter
             if rk in pm["fetch_kib"] and rk in pm["write_kib"]:
                 roofline["traffic"] = round((2.0 * pm["fetch_kib"][rk] + pm["write_kib"][rk]) * 1024.0)
                 roofline["traffic_source"] = pm.get("source", "profiles/")

@@ -48,6 +48,9 @@ typedef struct aloam_config {
   int device;              /* HIP device ordinal                                                                            */
   int lm_max_iterations;   /* options.max_num_iterations = 4 (reference src/laserOdometry.cpp:496)                          */
   int outer_iterations;    /* opti_counter loop = 2 (reference src/laserOdometry.cpp:278)                                   */
+  int distortion;          /* 0 = #define DISTORTION 0 (reference src/laserOdometry.cpp:59, the shipped setting); 1: every point is
+                              moved / constrained with its own interpolation ratio s = (intensity - int(intensity)) / SCAN_PERIOD
+                              (src/laserOdometry.cpp:115-116,376-377,474-475; src/lidarFactor.hpp:29-30,81-82)              */
 } aloam_config;
 
 /* Which cloud of a sequence (topic names of reference src/scanRegistration.cpp:480-488, src/laserOdometry.cpp:205-209). */

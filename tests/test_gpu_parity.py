@@ -241,3 +241,28 @@ def test_full_size_batch_properties(O, binding, syn):
     for b in range(B):
         assert bits_equal(g2.cloud(binding.CLOUD_LESS_FLAT, b), gpu.cloud(binding.CLOUD_SURF_LAST, b))
     g2.close(); gpu.close()
+
+
+def test_distortion_mode_matches_oracle(O, binding, sequence):
+    """DISTORTION 1 (compiled out in the reference's nodes, src/laserOdometry.cpp:59): per-point interpolation ratio in
+    TransformToStart and in the factors.  The device evaluates slerp with its own acos / sin, so a transformed query can round
+    differently in its last f32 bit: poses to the north-star tolerance, correspondence counts within a handful."""
+    scans, R, t, model = sequence("HDL-64", 4, seed=21, columns=1024)
+    orc = O.Oracle(n_scans=64, min_range=model.min_range, distortion=True)
+    ref = O.Oracle(n_scans=64, min_range=model.min_range)                 # s = 1, to show the mode does something
+    gpu = _mk(binding, model, max_points=70000, distortion=True)
+    moved = 0.0
+    for k, x in enumerate(scans):
+        _assert_features_equal(orc.scan_register(x), (gpu.scan_register(x), gpu.features())[1], ("distortion", k))
+        ref.scan_register(x)
+        po, pr = orc.odometry_step(), ref.odometry_step()
+        gpu.odometry_step()
+        pg = gpu.pose()
+        assert np.abs(po["t_lc"] - pg["t_lc"]).max() < 1e-6 and quat_angle(po["q_lc"], pg["q_lc"]) < 1e-6, (k, po, pg)
+        _assert_pose_close(po, pg, ("distortion", k))
+        so_, sg_ = orc.odom_stats(), gpu.odom_stats()
+        for key in ("corner_corr", "plane_corr"):
+            assert np.abs(np.array(so_[key]) - np.array(sg_[key])).max() <= 3, (k, key, so_, sg_)
+        moved = max(moved, np.abs(po["t_lc"] - pr["t_lc"]).max())
+    assert moved > 1e-4                                                   # not the s = 1 solution
+    gpu.close()
