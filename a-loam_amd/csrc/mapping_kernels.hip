@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256) void k_vox_keys_sort(VoxArgs v) {
     keys[e] = key;
   }
   __syncthreads();
-  const int in_tile = min(kVoxTile, sg.n - t * kVoxTile);                   // pads (all ones) beyond it are already in place
-  bitonic_sort_u64(keys, pow2ceil(in_tile), tid);
+  const int in_tile = min(kVoxTile, sg.n - t * kVoxTile);
+  bitonic_sort_u64(keys, in_tile, tid);
   unsigned long long* dst = v.keys[0] + sg.key_off;
   for (int e = tid; e < kVoxTile; e += 256) { const int i = t * kVoxTile + e; if (i < sg.n) dst[i] = keys[e]; }
   __syncthreads();

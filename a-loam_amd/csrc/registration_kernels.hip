@@ -599,10 +599,8 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
 #pragma unroll
   for (int it = 0; it < EIT; ++it)
     if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = ((unsigned long long)myvi[it] << 32) | (unsigned long long)e; }   // vis is dead: every thread read its share before the barrier
-  const int rpad = pow2ceil(n_runs > 1 ? n_runs : 1);
-  for (int q = n_runs + tid; q < rpad; q += 256) rkeys[q] = ~0ull;
   __syncthreads();
-  bitonic_sort_u64(rkeys, rpad, tid);
+  bitonic_sort_u64(rkeys, n_runs, tid);
 
   // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
   unsigned vmask = 0;
