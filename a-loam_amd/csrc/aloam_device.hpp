@@ -266,37 +266,46 @@ __device__ __forceinline__ int wave_scan_i32(int v) {
 // LDS bitonic sort of n 64-bit keys, ascending, 256 threads.  The network is the all-ascending form (a "flip" stage
 // i <-> block_end - i opens every merge, half-cleaners follow), so the slots n .. pow2ceil(n)-1 can stay imaginary +inf:
 // a pair whose upper partner lies beyond n is simply skipped, which removes a third of the LDS traffic at the typical
-// n ~ 0.7 * pow2ceil(n).  The stages that stay inside aligned groups of four keys (the merges k = 2 and 4, and the last
-// two half-cleaners of every later merge) run in registers: one read and one write of the group instead of one per stage.
+// n ~ 0.7 * pow2ceil(n).  The stages that stay inside aligned groups of eight keys (the merges k = 2, 4 and 8, and the last
+// three half-cleaners of every later merge) run in registers: one read and one write of the group instead of one per stage.
 // Starts and ends with the data visible to the whole workgroup.
 __device__ __forceinline__ void bitonic_cx(unsigned long long& a, unsigned long long& b) {
   const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo; b = hi;
 }
 template <bool FIRST>
-__device__ __forceinline__ void bitonic_groups_of_four(unsigned long long* keys, int n, int tid) {
-  for (int g = tid * 4; g < n; g += 1024) {
-    unsigned long long v[4];
+__device__ __forceinline__ void bitonic_groups_of_eight(unsigned long long* keys, int n, int tid) {
+  for (int g = tid * 8; g < n; g += 2048) {
+    unsigned long long v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = g + u < n ? keys[g + u] : ~0ull;
-    if (FIRST) {                                                             // merges k = 2 and k = 4
-      bitonic_cx(v[0], v[1]); bitonic_cx(v[2], v[3]);
-      bitonic_cx(v[0], v[3]); bitonic_cx(v[1], v[2]);
-      bitonic_cx(v[0], v[1]); bitonic_cx(v[2], v[3]);
-    } else {                                                                 // half-cleaners j = 2, j = 1
-      bitonic_cx(v[0], v[2]); bitonic_cx(v[1], v[3]);
-      bitonic_cx(v[0], v[1]); bitonic_cx(v[2], v[3]);
+    for (int u = 0; u < 8; ++u) v[u] = g + u < n ? keys[g + u] : ~0ull;
+    if (FIRST) {                                                             // merges k = 2, 4 and 8
+#pragma unroll
+      for (int b = 0; b < 8; b += 2) bitonic_cx(v[b], v[b + 1]);
+#pragma unroll
+      for (int b = 0; b < 8; b += 4) { bitonic_cx(v[b], v[b + 3]); bitonic_cx(v[b + 1], v[b + 2]); }
+#pragma unroll
+      for (int b = 0; b < 8; b += 2) bitonic_cx(v[b], v[b + 1]);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) bitonic_cx(v[o], v[7 - o]);
+    } else {                                                                 // half-cleaner j = 4
+#pragma unroll
+      for (int o = 0; o < 4; ++o) bitonic_cx(v[o], v[o + 4]);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) if (g + u < n) keys[g + u] = v[u];
+    for (int b = 0; b < 8; b += 4) { bitonic_cx(v[b], v[b + 2]); bitonic_cx(v[b + 1], v[b + 3]); }   // j = 2
+#pragma unroll
+    for (int b = 0; b < 8; b += 2) bitonic_cx(v[b], v[b + 1]);                                          // j = 1
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (g + u < n) keys[g + u] = v[u];
   }
   __syncthreads();
 }
 __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n, int tid) {
   int npad = 1;
   while (npad < n) npad <<= 1;
-  bitonic_groups_of_four<true>(keys, n, tid);
-  for (int k = 8; k <= npad; k <<= 1) {
+  bitonic_groups_of_eight<true>(keys, n, tid);
+  for (int k = 16; k <= npad; k <<= 1) {
     const int hk = k >> 1;
     for (int t = tid; t < (npad >> 1); t += 256) {                         // flip stage
       const int base = (t / hk) * k, off = t & (hk - 1);
@@ -307,7 +316,7 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n
       }
     }
     __syncthreads();
-    for (int j = k >> 2; j > 2; j >>= 1) {
+    for (int j = k >> 2; j > 4; j >>= 1) {
       for (int t = tid; t < (npad >> 1); t += 256) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         const int l = i + j;
@@ -318,7 +327,7 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n
       }
       __syncthreads();
     }
-    bitonic_groups_of_four<false>(keys, n, tid);
+    bitonic_groups_of_eight<false>(keys, n, tid);
   }
 }
 
