@@ -111,6 +111,19 @@ struct ProfScope {
     if (c->prof_on) { hipEvent_t e1 = prof_event(c); (void)hipEventRecord(e1, c->stream); c->prof_pending.push_back({k, e0, e1}); }
   }
 };
+// Every entry point runs on the context's device whatever the calling thread's current device is, and leaves the caller's
+// choice as it found it (several contexts on several devices in one process; frameworks that switch devices behind our back).
+struct DeviceScope {
+  int prev = -1;
+  explicit DeviceScope(const aloam_ctx* c) {
+    int cur = -1;
+    if (c && hipGetDevice(&cur) == hipSuccess && cur != c->cfg.device && hipSetDevice(c->cfg.device) == hipSuccess) prev = cur;
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceScope(const DeviceScope&) = delete;
+  DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 void prof_resolve(aloam_ctx* c) {
   for (ProfRec& r : c->prof_pending) {
     float ms = 0.f;
@@ -279,6 +292,7 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
 }
 
 void aloam_destroy(aloam_ctx* c) {
+  DeviceScope device_scope(c);
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   prof_resolve(c);
@@ -304,6 +318,7 @@ const char* aloam_last_error(const aloam_ctx* c) { return c ? c->err.c_str() : "
 void* aloam_stream(aloam_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int aloam_synchronize(aloam_ctx* c) {
+  DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   std::vector<SeqMeta> m(c->B);
@@ -324,11 +339,13 @@ int aloam_synchronize(aloam_ctx* c) {
 }
 
 int aloam_scan_register_device(aloam_ctx* c, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
+  DeviceScope device_scope(c);
   if (!c || !d_scans || !n_in) return ALOAM_E_ARG;
   return register_launch(c, d_scans, seq_stride_bytes, n_in, stride_bytes);
 }
 
 int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in, int stride_bytes) {
+  DeviceScope device_scope(c);
   if (!c || !scans || !n_in) return ALOAM_E_ARG;
   if (stride_bytes < 16) { c->err = "stride_bytes must be >= 16"; return ALOAM_E_ARG; }
   const size_t seq_stride = (size_t)c->cap * stride_bytes;
@@ -349,6 +366,7 @@ int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in,
 }
 
 int aloam_odometry_step(aloam_ctx* c) {
+  DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
   if (!c->have_features) { c->err = "aloam_odometry_step before any features were registered / set"; return ALOAM_E_STATE; }
   if (!c->system_inited) {
@@ -372,6 +390,7 @@ int aloam_odometry_step(aloam_ctx* c) {
 }
 
 int aloam_process_device(aloam_ctx* c, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
+  DeviceScope device_scope(c);
   const int rc = aloam_scan_register_device(c, d_scans, seq_stride_bytes, n_in, stride_bytes);
   if (rc) return rc;
   return aloam_odometry_step(c);
@@ -395,6 +414,7 @@ static int cloud_ref(aloam_ctx* c, int seq, int which, const SeqMeta& m, const f
 }
 
 int aloam_cloud_size(aloam_ctx* c, int seq, int which) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   SeqMeta m;
@@ -405,6 +425,7 @@ int aloam_cloud_size(aloam_ctx* c, int seq, int which) {
 }
 
 int aloam_get_cloud(aloam_ctx* c, int seq, int which, float* out, int cap_points) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   SeqMeta m;
@@ -417,6 +438,7 @@ int aloam_get_cloud(aloam_ctx* c, int seq, int which, float* out, int cap_points
 }
 
 int aloam_get_pose(aloam_ctx* c, int seq, double q_w[4], double t_w[3], double q_lc[4], double t_lc[3]) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if ((rc = sync_and_check(c))) return rc;
@@ -428,6 +450,7 @@ int aloam_get_pose(aloam_ctx* c, int seq, double q_w[4], double t_w[3], double q
 }
 
 int aloam_get_odom_stats(aloam_ctx* c, int seq, aloam_odom_stats* out) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if ((rc = sync_and_check(c))) return rc;
@@ -444,6 +467,7 @@ int aloam_get_odom_stats(aloam_ctx* c, int seq, aloam_odom_stats* out) {
 // ---- state injection -----------------------------------------------------------------------------------------
 int aloam_set_features(aloam_ctx* c, int seq, const float* sharp, int n_sharp, const float* less_sharp, int n_less_sharp,
                        const float* flat, int n_flat, const float* less_flat, int n_less_flat) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if (n_sharp < 0 || n_sharp > c->R * 12 || n_less_sharp < 0 || n_less_sharp > c->R * 120 || n_flat < 0 || n_flat > c->R * 24 ||
@@ -463,6 +487,7 @@ int aloam_set_features(aloam_ctx* c, int seq, const float* sharp, int n_sharp, c
 }
 
 int aloam_set_last(aloam_ctx* c, int seq, const float* corner_last, int n_corner, const float* surf_last, int n_surf) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if (n_corner < 0 || n_corner > c->R * 120 || n_surf < 0 || n_surf > c->cap) { c->err = "last cloud too large"; return ALOAM_E_CAPACITY; }
@@ -478,6 +503,7 @@ int aloam_set_last(aloam_ctx* c, int seq, const float* corner_last, int n_corner
 }
 
 int aloam_set_state(aloam_ctx* c, int seq, const double para_q[4], const double para_t[3], const double q_w[4], const double t_w[3]) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -490,6 +516,7 @@ int aloam_set_state(aloam_ctx* c, int seq, const double para_q[4], const double 
 }
 
 int aloam_set_system_inited(aloam_ctx* c, int inited) {
+  DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
   c->system_inited = inited != 0;
   return ALOAM_OK;
@@ -497,6 +524,7 @@ int aloam_set_system_inited(aloam_ctx* c, int inited) {
 
 // ---- intermediate arrays ---------------------------------------------------------------------------------------
 int aloam_get_ring_ranges(aloam_ctx* c, int seq, int* start, int* count) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if ((rc = sync_and_check(c))) return rc;
@@ -507,6 +535,7 @@ int aloam_get_ring_ranges(aloam_ctx* c, int seq, int* start, int* count) {
 }
 
 int aloam_get_curvature(aloam_ctx* c, int seq, float* out, int cap) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   SeqMeta m;
@@ -517,6 +546,7 @@ int aloam_get_curvature(aloam_ctx* c, int seq, float* out, int cap) {
 }
 
 int aloam_get_labels(aloam_ctx* c, int seq, int* out, int cap) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   SeqMeta m;
@@ -530,6 +560,7 @@ int aloam_get_labels(aloam_ctx* c, int seq, int* out, int cap) {
 
 int aloam_get_correspondences(aloam_ctx* c, int seq, float* edges, int cap_edges, int* n_edges, int* edge_query,
                               float* planes, int cap_planes, int* n_planes, int* plane_query) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   SeqMeta m;
@@ -564,6 +595,7 @@ int aloam_get_correspondences(aloam_ctx* c, int seq, float* edges, int cap_edges
 
 // ---- profiling -----------------------------------------------------------------------------------------------
 int aloam_profile_enable(aloam_ctx* c, int on) {
+  DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   prof_resolve(c);
@@ -575,6 +607,7 @@ int aloam_profile_kernel_count(void) { return K_COUNT; }
 const char* aloam_profile_kernel_name(int k) { return (k >= 0 && k < K_COUNT) ? kKernelNames[k] : ""; }
 
 int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* launches, double* algorithmic_bytes) {
+  DeviceScope device_scope(c);
   if (!c || kernel < 0 || kernel >= K_COUNT) return ALOAM_E_ARG;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   prof_resolve(c);
@@ -640,6 +673,7 @@ static VoxArgs vox_args(aloam_ctx* c, int n_segs, int levels) {
 }
 
 int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool_points) {
+  DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
   if (c->map_on) { c->err = "mapping already enabled"; return ALOAM_E_STATE; }
   if (!(line_res > 0.f) || !(plane_res > 0.f) || pool_points < 4096) { c->err = "bad mapping parameters (pool_points >= 4096)"; return ALOAM_E_ARG; }
@@ -700,6 +734,7 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
 }
 
 int aloam_mapping_step(aloam_ctx* c) {
+  DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
   if (!c->map_on) { c->err = "aloam_mapping_step before aloam_mapping_enable"; return ALOAM_E_STATE; }
   const MapArgs a = map_args(c);
@@ -724,6 +759,7 @@ int aloam_mapping_step(aloam_ctx* c) {
 }
 
 int aloam_set_full_cloud(aloam_ctx* c, int seq, const float* cloud, int n) {
+  DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if (n < 0 || n > c->cap) { c->err = "cloud too large"; return ALOAM_E_CAPACITY; }
@@ -746,6 +782,7 @@ static int fetch_mapseq(aloam_ctx* c, int seq, MapSeq* ms) {
 }
 
 int aloam_get_map_pose(aloam_ctx* c, int seq, double q_w_curr[4], double t_w_curr[3], double q_wmap_wodom[4], double t_wmap_wodom[3]) {
+  DeviceScope device_scope(c);
   MapSeq ms;
   const int rc = fetch_mapseq(c, seq, &ms);
   if (rc) return rc;
@@ -755,6 +792,7 @@ int aloam_get_map_pose(aloam_ctx* c, int seq, double q_w_curr[4], double t_w_cur
 }
 
 int aloam_get_map_info(aloam_ctx* c, int seq, int out[16]) {
+  DeviceScope device_scope(c);
   MapSeq ms;
   const int rc = fetch_mapseq(c, seq, &ms);
   if (rc) return rc;
@@ -766,6 +804,7 @@ int aloam_get_map_info(aloam_ctx* c, int seq, int out[16]) {
 }
 
 int aloam_map_cube_counts(aloam_ctx* c, int seq, int cls, int* out) {
+  DeviceScope device_scope(c);
   MapSeq ms;
   const int rc = fetch_mapseq(c, seq, &ms);
   if (rc) return rc;
@@ -777,6 +816,7 @@ int aloam_map_cube_counts(aloam_ctx* c, int seq, int cls, int* out) {
 }
 
 int aloam_get_map_cube(aloam_ctx* c, int seq, int cls, int cube, float* out, int cap_points) {
+  DeviceScope device_scope(c);
   MapSeq ms;
   const int rc = fetch_mapseq(c, seq, &ms);
   if (rc) return rc;
@@ -789,6 +829,7 @@ int aloam_get_map_cube(aloam_ctx* c, int seq, int cls, int cube, float* out, int
 }
 
 int aloam_get_map_cloud(aloam_ctx* c, int seq, int which, float* out, int cap_points) {
+  DeviceScope device_scope(c);
   MapSeq ms;
   const int rc = fetch_mapseq(c, seq, &ms);
   if (rc) return rc;

@@ -11,6 +11,7 @@
  *   - one aloam_ctx = `batch` independent sequences advanced in lock-step on ONE device and ONE HIP stream
  *     (batch = 1 is the reference's single-sensor node).  A context is not thread-safe; distinct contexts
  *     are independent (one per GPU / per process for multi-GPU; no collectives — sequences never exchange data).
+ *     Every call runs on the context's device and restores the calling thread's current HIP device before returning.
  *   - points are 16-byte records {float x, y, z, w}; w = `intensity` of pcl::PointXYZI
  *     (reference include/aloam_velodyne/common.h:43).  Input records may use any stride >= 16 bytes
  *     (32 = the PointCloud2 point_step pcl::toROSMsg<PointXYZI> produces, reference src/kittiHelper.cpp:153-154).
