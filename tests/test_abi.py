@@ -65,3 +65,34 @@ def test_no_cpu_fallback_without_a_device(binding):
     with pytest.raises(binding.AloamError) as e:
         binding.Aloam(n_scans=16, min_range=0.3, max_points=30000)
     assert e.value.code == binding.E_HIP
+
+
+def test_ctypes_mirrors_match_the_header_layout(binding, tmp_path):
+    """The structures of a-loam_amd/binding.py against what a C compiler makes of include/aloam_mi355x.h: same size, same
+    field names in the same order at the same offsets (catches a field added on one side only), distortion defaulting to 0."""
+    fields = {"aloam_config": [n for n, _ in binding.AloamConfig._fields_], "aloam_odom_stats": [n for n, _ in binding.AloamOdomStats._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{binding.HEADER_PATH}"', "int main(void) {"]
+    for st, names in fields.items():
+        src.append(f'  printf("{st} %zu", sizeof({st}));')
+        for n in names:
+            src.append(f'  printf(" {n}:%zu", offsetof({st}, {n}));')
+        src.append('  printf("\\n");')
+    src += ["  return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    for line, (st, cls) in zip(out, (("aloam_config", binding.AloamConfig), ("aloam_odom_stats", binding.AloamOdomStats))):
+        parts = line.split()
+        assert parts[0] == st and int(parts[1]) == C.sizeof(cls), line
+        for tok, (name, _) in zip(parts[2:], cls._fields_):
+            n, off = tok.split(":")
+            assert n == name and int(off) == getattr(cls, name).offset, (st, tok)
+    hdr = re.sub(r"/\*.*?\*/", "", open(binding.HEADER_PATH).read(), flags=re.S)
+    body = re.search(r"typedef struct aloam_config \{(.*?)\} aloam_config;", hdr, flags=re.S).group(1)
+    declared = re.findall(r"\b(\w+)\s*;", body)
+    assert declared == fields["aloam_config"], (declared, fields["aloam_config"])
+    cfg = binding.AloamConfig()
+    binding.lib().aloam_default_config(C.byref(cfg))
+    assert cfg.distortion == 0                                             # #define DISTORTION 0 (laserOdometry.cpp:59)
