@@ -107,6 +107,50 @@ def test_factor_jacobians_autodiff_vs_closed_form_vs_central_differences(O, kind
         assert np.allclose(J_fd, J_cf, rtol=1e-5, atol=1e-6 * max(1.0, np.abs(J_cf).max()))
 
 
+@pytest.mark.parametrize("kind,n", [(0, 9), (1, 12)])
+def test_factor_jacobians_with_interpolation_ratio(O, kind, n):
+    """DISTORTION 1: the functors with a general interpolation ratio s.  s = 1 reproduces the default evaluation bit for bit; for
+    other s the dual-number Jacobian equals central differences on the manifold, and an independent numpy restatement of
+    lp = slerp(I, q, s) * cp + s t gives the same residual."""
+    rng = np.random.default_rng(40 + kind)
+    for it in range(60):
+        consts = rng.normal(size=n) * 10
+        q, t = _random_pose(rng)
+        r1, J1 = O.factor_eval_s(kind, consts, 1.0, q, t)
+        r0, J0 = O.factor_eval(kind, consts, q, t, analytic=False)
+        assert np.array_equal(r1, r0) and np.array_equal(J1, J0)
+        s = [0.0, 0.3, 0.999, 1.7, 9.9][it % 5]                              # > 1 happens: intensity = ring - eps (SURVEY quirk 2)
+        r, J = O.factor_eval_s(kind, consts, s, q, t)
+        # independent restatement of the interpolated transform
+        w = np.clip(abs(q[3]), -1, 1)
+        if w >= 1.0 - np.finfo(float).eps:
+            c0, c1 = 1 - s, s
+        else:
+            th = np.arccos(w); c0, c1 = np.sin((1 - s) * th) / np.sin(th), np.sin(s * th) / np.sin(th)
+        if q[3] < 0:
+            c1 = -c1
+        u, ww = c1 * q[:3], c0 + c1 * q[3]
+        cp = consts[:3]
+        uv = 2 * np.cross(u, cp)
+        lp = cp + ww * uv + np.cross(u, uv) + s * t
+        if kind == 0:
+            a, b = consts[3:6], consts[6:9]
+            ref = np.cross(lp - a, lp - b) / np.linalg.norm(a - b)
+        else:
+            j, l, m = consts[3:6], consts[6:9], consts[9:12]
+            nrm = np.cross(j - l, j - m); nrm /= np.linalg.norm(nrm)
+            ref = np.array([(lp - j) @ nrm])
+        assert np.allclose(r, ref, rtol=1e-11, atol=1e-11)
+        h = 1e-6
+        J_fd = np.zeros_like(J)
+        for k in range(6):
+            d = np.zeros(6); d[k] = h
+            rp, _ = O.factor_eval_s(kind, consts, s, O.quat_plus(q, d[:3]), t + d[3:])
+            rm, _ = O.factor_eval_s(kind, consts, s, O.quat_plus(q, -d[:3]), t - d[3:])
+            J_fd[:, k] = (rp - rm) / (2 * h)
+        assert np.allclose(J_fd, J, rtol=2e-5, atol=2e-6 * max(1.0, np.abs(J).max())), (kind, s, J_fd, J)
+
+
 def test_edge_residual_is_point_to_line_distance(O):
     rng = np.random.default_rng(5)
     a, b, cp = rng.normal(size=3), rng.normal(size=3), rng.normal(size=3) * 3
