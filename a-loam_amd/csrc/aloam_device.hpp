@@ -205,12 +205,6 @@ __device__ __forceinline__ double shfl_down_f64(double v, int d) {
   hi = __shfl_down(hi, d, 64);
   return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
-  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-  lo = __shfl_xor(lo, m, 64);
-  hi = __shfl_xor(hi, m, 64);
-  return ((unsigned long long)hi << 32) | lo;
-}
 
 // ---- wave-wide max / min of a 64-bit key without touching the LDS crossbar ---------------------------------------
 // value of lane ^ D inside a row of 16 lanes: D = 1, 2 one DPP quad permute; D = 4, 8 two DPP row shifts + a select.
@@ -269,6 +263,7 @@ __device__ __forceinline__ int wave_scan_i32(int v) {
 // n ~ 0.7 * pow2ceil(n).  The stages that stay inside aligned groups of eight keys (the merges k = 2, 4 and 8, and the last
 // three half-cleaners of every later merge) run in registers: one read and one write of the group instead of one per stage.
 // Starts and ends with the data visible to the whole workgroup.
+__device__ __forceinline__ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 __device__ __forceinline__ void bitonic_cx(unsigned long long& a, unsigned long long& b) {
   const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo; b = hi;
@@ -302,8 +297,7 @@ __device__ __forceinline__ void bitonic_groups_of_eight(unsigned long long* keys
   __syncthreads();
 }
 __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n, int tid) {
-  int npad = 1;
-  while (npad < n) npad <<= 1;
+  const int npad = pow2ceil(n);
   bitonic_groups_of_eight<true>(keys, n, tid);
   for (int k = 16; k <= npad; k <<= 1) {
     const int hk = k >> 1;
@@ -331,6 +325,5 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n
   }
 }
 
-__device__ __forceinline__ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 }  // namespace aloam
