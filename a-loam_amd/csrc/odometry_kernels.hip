@@ -8,8 +8,10 @@
 //   k_associate   TransformToStart (:111-129) + nearestKSearch(k=1) (:302,390) + the ring-adjacent second / third
 //                 neighbour walks (:304-384, :392-482), one wave per query: exact 1-NN by expanding cubic shells of
 //                 hash cells with the f32 distance ((dx*dx+dy*dy)+dz*dz) FLANN's L2_Simple accumulates (lowest index
-//                 wins exact ties), then the walk candidates through the (x, y, ring) grid; clouds that are not
-//                 ring-sorted fall back to the literal brute-force loops inside the same kernel
+//                 wins exact ties); the walk candidates come first from the 1-NN block's own candidates, then from the
+//                 (x, y, ring) grid; clouds that are not ring-sorted fall back to the literal loops inside the same
+//                 kernel.  With aloam_config.distortion the per-point interpolation ratio of DISTORTION 1 is applied
+//                 (:115-116, :376-377, :474-475; separate template instantiations)
 //   k_solve       ceres::Problem + ceres::Solve (:284-291,380-381,478-479,494-499): per-correspondence
 //                 LidarEdgeFactor / LidarPlaneFactor residual + closed-form Jacobian (reference src/lidarFactor.hpp:
 //                 18-43,68-90), Huber(0.1) re-weighting, reduction to the 6x6 J^T J / J^T r / cost with wave64
@@ -469,8 +471,6 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
         const int j = (int)(wb & kIdxMask), pk = (int)(wb >> 20) - 1;
         if (pk >= cid - 2 && pk <= cid + 2) consider(p, j, pk);
       };
-      // level 0: the 3x3 block of fine cells, 5 ring keys each (45 look-ups, one per lane); level 1, only if a neighbour may
-      // still be farther than the fine block reaches: the 3x3 block of coarse cells, which covers DISTANCE_SQ_THRESHOLD
       // On a ring-sorted cloud the second neighbour of a planar feature is the nearest point of the closest point's own ring
       // and the third the nearest of the other rings; a corner feature's second neighbour comes from the other rings only.
       bool done2 = false, done3 = !PLANE;
