@@ -2,7 +2,8 @@
 //
 // Replaces, for a BATCH of independent sequences, the body of process() in the reference's src/laserMapping.cpp:231-893
 // (one frame per call, no frame dropping) and the third-party calls inside it.  Kernel <-> reference map:
-//   k_map_compact_*    (no counterpart: the reference's cubes are std::vectors) packs the class pools when half is handed out
+//   k_map_compact_*    (no counterpart: the reference's cubes are std::vectors) packs the class pools when a frame's growth
+//                      no longer fits behind the bump pointer
 //   k_map_begin        :142-146 transformAssociateToMap, :311-321 centre cube, :323-507 window shifts (the 21 x 21 x 11
 //                      pointer grid becomes a table of cube descriptors), :509-539 valid cubes + submap prefixes
 //   k_vox_*            pcl::VoxelGrid::filter (:542-550 incoming clouds, :788-801 per-cube re-filter): bounding box ->

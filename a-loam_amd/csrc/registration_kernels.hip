@@ -7,9 +7,10 @@
 //                                per-block ring histograms
 //   k_ring_offsets    :246-252   ring start offsets (exclusive scans of the histograms)
 //   k_scatter         :208-241   relTime -> intensity, STABLE per-ring compaction into the ring-ordered cloud
-//   k_ring_features   :256-407   one workgroup per (sweep, ring): 11-tap curvature from an LDS tile, 6-sector
-//                                sort (LDS bitonic), greedy corner / flat picking with neighbour suppression,
-//                                less-flat gather + 0.2 m voxel centroids (pcl::VoxelGrid stand-in)
+//   k_ring_features   :256-407   one workgroup per (sweep, ring): 11-tap curvature from alternating 266-point LDS
+//                                tiles; std::sort + greedy corner / flat picking with neighbour suppression evaluated as
+//                                an iterative arg-max per sector (no sort); less-flat gather + 0.2 m voxel centroids
+//                                (pcl::VoxelGrid stand-in: runs of same-voxel points sorted by an LDS bitonic)
 //   k_compact_features :304-310,356,407  append per-(ring,sector) picks in the reference's output order
 //
 // All of it is HBM/latency-bound integer + f32 work: coalesced 16-B loads, LDS staging, wave64 ballots; no MFMA.
