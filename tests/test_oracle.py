@@ -358,3 +358,53 @@ def test_oracle_reproduces_committed_goldens(O, path):
             assert np.allclose(p[key], g[f"{key}{k}"], rtol=0, atol=1e-9), (path, k, key)
         k += 1
     assert k >= 2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# third-party stand-ins of the mapping stage: KdTreeFLANN k = 5, SelfAdjointEigenSolver, colPivHouseholderQr
+def test_knn5_equals_brute_force_and_scipy(O):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(70)
+    tgt = np.zeros((6000, 4), np.float32); tgt[:, :3] = rng.uniform(-20, 20, (6000, 3))
+    qry = np.zeros((500, 4), np.float32); qry[:, :3] = rng.uniform(-22, 22, (500, 3))
+    i_tree, d_tree = O.knn_search(tgt, qry, 5)
+    i_bf, d_bf = O.knn_search(tgt, qry, 5, brute=True)
+    assert np.array_equal(i_tree, i_bf) and bits_equal(d_tree, d_bf)
+    assert np.all(np.diff(d_tree, axis=1) >= 0)                                           # ascending, like nearestKSearch
+    _, i_sp = cKDTree(tgt[:, :3].astype(np.float64)).query(qry[:, :3].astype(np.float64), k=5)
+    same = (i_sp == i_tree).all(axis=1)
+    assert same.mean() > 0.99                                                             # f32 vs f64 distances may swap near-ties
+    for r in np.where(~same)[0]:
+        assert set(i_sp[r]) == set(i_tree[r]) or np.allclose(np.sort(d_tree[r]), np.sort(((tgt[i_sp[r], :3] - qry[r, :3]) ** 2).sum(1)), rtol=1e-5)
+    few = O.knn_search(tgt[:3], qry[:4], 5)                                                # k clipped to the cloud size
+    assert few[0].shape == (4, 5)
+
+
+def test_sym_eigen3_matches_numpy(O):
+    rng = np.random.default_rng(71)
+    for it in range(200):
+        P = rng.normal(size=(5, 3)) * (10.0 ** rng.uniform(-2, 1))
+        if it % 4 == 0:
+            P = np.outer(rng.normal(size=5), rng.normal(size=3)) + 1e-3 * rng.normal(size=(5, 3))   # nearly a line, like a corner fit
+        c = P - P.mean(0)
+        A = c.T @ c / 5.0
+        vals, vecs = O.sym_eigen3(A)
+        w, V = np.linalg.eigh(A)
+        assert np.allclose(vals, w, rtol=1e-9, atol=1e-12 * max(1.0, w[-1]))
+        assert np.all(np.diff(vals) >= 0)
+        assert np.allclose(vecs.T @ vecs, np.eye(3), atol=1e-9)                            # orthonormal columns
+        assert np.allclose(A @ vecs, vecs * vals, atol=1e-9 * max(1.0, w[-1]))
+        if w[2] - w[1] > 1e-6 * w[2]:
+            assert abs(abs(vecs[:, 2] @ V[:, 2]) - 1.0) < 1e-8                            # principal direction (sign free)
+
+
+def test_lstsq_5x3_matches_numpy(O):
+    rng = np.random.default_rng(72)
+    for _ in range(200):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        pts = rng.normal(size=(5, 3)) * 3
+        pts -= np.outer(pts @ n - 2.0, n) * 0.98                                          # five points near the plane n . x = 2
+        b = -np.ones(5)
+        x = O.lstsq_5x3(pts, b)
+        ref = np.linalg.lstsq(pts, b, rcond=None)[0]
+        assert np.allclose(x, ref, rtol=1e-8, atol=1e-10), (x, ref)
