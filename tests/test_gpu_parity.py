@@ -266,3 +266,42 @@ def test_distortion_mode_matches_oracle(O, binding, sequence):
         moved = max(moved, np.abs(po["t_lc"] - pr["t_lc"]).max())
     assert moved > 1e-4                                                   # not the s = 1 solution
     gpu.close()
+
+
+@pytest.mark.xfail(strict=False, reason="written after this round's GPU budget was spent: never run on hardware yet; promote to a plain test once it has passed")
+@pytest.mark.parametrize("mode", ["unsorted", "far"])
+def test_last_clouds_that_are_not_ring_sorted_or_out_of_range(O, binding, sequence, mode):
+    """aloam_set_last accepts any cloud.  'unsorted': ring keys not ascending -> the literal walk loops (:312-361 / :402-455)
+    instead of the ring-key window; 'far': a coordinate beyond the range the cell arithmetic is exact for -> literal brute-force
+    1-NN as well.  Both must give the oracle's correspondences (the oracle always walks literally)."""
+    scans, R, t, model = sequence("HDL-64", 3, seed=8, columns=1024)
+    orc = O.Oracle(n_scans=64, min_range=model.min_range)
+    feats = []
+    for x in scans:
+        feats.append(orc.scan_register(x))
+        orc.odometry_step()
+    rng = np.random.default_rng(3)
+    corner, surf = feats[1]["less_sharp"].copy(), feats[1]["less_flat"].copy()
+    if mode == "unsorted":
+        for c in (corner, surf):                                              # swap two blocks of rings: keys go down once
+            k = len(c) // 2
+            c[:] = np.concatenate([c[k:], c[:k]])
+    else:
+        surf[rng.integers(len(surf))][:3] = (5000.0, 10.0, 1.0)
+        corner[rng.integers(len(corner))][:3] = (-4200.0, 0.0, 0.0)
+    para_q, para_t = np.array([0.0, 0.0, 0.01, 1.0]), np.array([0.95, 0.02, 0.0])
+    para_q /= np.linalg.norm(para_q)
+    o2 = O.Oracle(n_scans=64, min_range=model.min_range)
+    gpu = _mk(binding, model, max_points=70000)
+    for dev in (o2, gpu):
+        dev.set_features(feats[2])
+        dev.set_last(corner, surf)
+        dev.set_state(para_q, para_t, [0, 0, 0, 1.0], [0, 0, 0.0], inited=True)
+        dev.odometry_step()
+    eo, plo, eqo, pqo = o2.correspondences()
+    eg, plg, eqg, pqg = gpu.correspondences()
+    assert np.array_equal(eqo, eqg) and np.array_equal(pqo, pqg)
+    assert bits_equal(eo.astype(np.float32), eg) and bits_equal(plo.astype(np.float32), plg)
+    _assert_pose_close(o2.pose(), gpu.pose(), mode)
+    assert o2.odom_stats()["plane_corr"] == gpu.odom_stats()["plane_corr"] and min(o2.odom_stats()["plane_corr"]) > 100
+    gpu.close()
