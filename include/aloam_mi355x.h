@@ -66,7 +66,7 @@ enum {
 };
 
 typedef struct aloam_odom_stats {
-  int corner_corr[2];      /* corner_correspondence per outer iteration (reference src/laserOdometry.cpp:382) */
+  int corner_corr[2];      /* corner_correspondence (reference src/laserOdometry.cpp:382): [0] first outer iteration, [1] second — or the last one when outer_iterations > 2 */
   int plane_corr[2];       /* plane_correspondence  per outer iteration (reference src/laserOdometry.cpp:480) */
   int lm_iterations[2];    /* LM iterations executed per ceres::Solve stand-in                                 */
   int lm_successful[2];

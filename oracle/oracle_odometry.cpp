@@ -196,20 +196,17 @@ int odometry_step(const orc_config& cfg, const std::vector<P4>& sharp, const std
           }
         }
       }
-      if (opti < 2) {
-        st->stats.corner_corr[opti] = (int)st->edges.size();
-        st->stats.plane_corr[opti] = (int)st->planes.size();
-      }
+      const int slot = opti < 2 ? opti : 1;     // [0] first outer iteration, [1] second or, with more than two, the last one
+      st->stats.corner_corr[slot] = (int)st->edges.size();
+      st->stats.plane_corr[slot] = (int)st->planes.size();
       // ---- ceres::Solve (:494-499)
       const LmSummary sm = lm_solve(st->edges, st->planes, st->para_q, st->para_t, cfg.lm_max_iterations,
                                     cfg.analytic_jacobian != 0, cfg.apply_converged_step != 0);
-      if (opti < 2) {
-        st->stats.lm_iterations[opti] = sm.iterations;
-        st->stats.lm_successful[opti] = sm.successful;
-        st->stats.initial_cost[opti] = sm.initial_cost;
-        st->stats.final_cost[opti] = sm.final_cost;
-        st->stats.termination[opti] = sm.termination;
-      }
+      st->stats.lm_iterations[slot] = sm.iterations;
+      st->stats.lm_successful[slot] = sm.successful;
+      st->stats.initial_cost[slot] = sm.initial_cost;
+      st->stats.final_cost[slot] = sm.final_cost;
+      st->stats.termination[slot] = sm.termination;
     }
     // ---- pose integration (:504-505), no renormalisation
     const Quatd q_lc{st->para_q[0], st->para_q[1], st->para_q[2], st->para_q[3]};

@@ -305,3 +305,22 @@ def test_last_clouds_that_are_not_ring_sorted_or_out_of_range(O, binding, sequen
     _assert_pose_close(o2.pose(), gpu.pose(), mode)
     assert o2.odom_stats()["plane_corr"] == gpu.odom_stats()["plane_corr"] and min(o2.odom_stats()["plane_corr"]) > 100
     gpu.close()
+
+
+@pytest.mark.xfail(strict=False, reason="written after this round's GPU budget was spent: never run on hardware yet; promote to a plain test once it has passed")
+@pytest.mark.parametrize("outer,lm", [(1, 4), (3, 2), (2, 8), (2, 0)])
+def test_solver_settings_other_than_the_reference_defaults(O, binding, sequence, outer, lm):
+    """opti_counter loop (src/laserOdometry.cpp:278) and options.max_num_iterations (:496) are configuration here; the
+    device loop must follow the oracle for other values too (lm = 0: evaluation only, the pose stays at the warm start)."""
+    scans, R, t, model = sequence("HDL-64", 3, seed=9, columns=512)
+    orc = O.Oracle(n_scans=64, min_range=model.min_range, outer_iterations=outer, lm_max_iterations=lm)
+    gpu = _mk(binding, model, max_points=40000, outer_iterations=outer, lm_max_iterations=lm)
+    for k, x in enumerate(scans):
+        _assert_features_equal(orc.scan_register(x), (gpu.scan_register(x), gpu.features())[1], (outer, lm, k))
+        po = orc.odometry_step()
+        gpu.odometry_step()
+        _assert_pose_close(po, gpu.pose(), (outer, lm, k))
+        so_, sg_ = orc.odom_stats(), gpu.odom_stats()
+        for key in ("corner_corr", "plane_corr", "lm_iterations", "lm_successful", "termination"):
+            assert so_[key] == sg_[key], (outer, lm, k, key, so_, sg_)
+    gpu.close()
