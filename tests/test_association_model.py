@@ -197,3 +197,32 @@ def test_grid_search_model_equals_the_walk_until_break_definition(plane, cell3, 
             got = model_query(sel, g3, g3c, g2, plane, 3 if plane else 2)
             want = reference_query(sel, pts, keys, plane)
             assert got == want, (plane, cell3, H, seed, trial, qi, sel, got, want)
+
+
+def test_map_search_block_model_equals_brute_force():
+    """k_map_search (a-loam_amd/csrc/mapping_kernels.hip): 2 m cells, the 2x2x2 block on the query's side of its cell, duplicate
+    buckets walked once, no per-candidate cell test — must find exactly the points with d < 1 m, and from them the five
+    smallest (distance, index), which is what the reference uses of nearestKSearch(k = 5) (src/laserMapping.cpp:582,650)."""
+    rng = np.random.default_rng(11)
+    for H in (8, 64, 4096):
+        n = 3000
+        pts = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
+        snap = rng.random(n) < 0.3
+        pts[snap] = np.round(pts[snap] * 2) / 2                                # many points on cell borders / exact ties
+        buckets = [[] for _ in range(H)]
+        for i, p in enumerate(pts):
+            buckets[_hash3(int(np.floor(F(p[0]) * F(0.5))), int(np.floor(F(p[1]) * F(0.5))), int(np.floor(F(p[2]) * F(0.5))), H)].append(i)
+        qs = np.concatenate([pts[rng.integers(0, n, 150)] + rng.normal(scale=0.3, size=(150, 3)).astype(np.float32),
+                             np.round(rng.uniform(-9, 9, (50, 3)) * 2).astype(np.float32) / 2])
+        for sel in qs.astype(np.float32):
+            g = [F(sel[k]) * F(0.5) for k in range(3)]
+            c = [int(np.floor(v)) for v in g]
+            nb = [c[k] + 1 if F(g[k] - F(c[k])) >= F(0.5) else c[k] - 1 for k in range(3)]
+            hs = []
+            for m in range(8):
+                h = _hash3(nb[0] if m & 1 else c[0], nb[1] if m & 2 else c[1], nb[2] if m & 4 else c[2], H)
+                if h not in hs:
+                    hs.append(h)
+            found = sorted((float(_d2(pts[i], sel)), i) for h in hs for i in buckets[h] if _d2(pts[i], sel) < F(1.0))[:5]
+            want = sorted((float(_d2(p, sel)), i) for i, p in enumerate(pts) if _d2(p, sel) < F(1.0))[:5]
+            assert found == want, (H, sel, found, want)
