@@ -7,7 +7,7 @@ import pandas as pd
 def main(d, out):
     cc = pd.concat([pd.read_csv(f) for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)])
     cc = cc[cc.Kernel_Name.str.contains("aloam::")]
-    cc["kernel"] = cc.Kernel_Name.str.extract(r"aloam::(\w+(?:<\w+>)?)")
+    cc["kernel"] = cc.Kernel_Name.str.extract(r"aloam::(\w+(?:<[^>]*>)?)")
     piv = cc.pivot_table(index="kernel", columns="Counter_Name", values="Counter_Value", aggfunc="mean")
     cnt = cc.groupby("kernel").Dispatch_Id.nunique().rename("dispatches")
     piv = piv.join(cnt)
@@ -15,7 +15,7 @@ def main(d, out):
     if kts:
         kt = pd.concat([pd.read_csv(f) for f in kts])
         kt = kt[kt.Kernel_Name.str.contains("aloam::")]
-        kt["kernel"] = kt.Kernel_Name.str.extract(r"aloam::(\w+(?:<\w+>)?)")
+        kt["kernel"] = kt.Kernel_Name.str.extract(r"aloam::(\w+(?:<[^>]*>)?)")
         kt["us"] = (kt.End_Timestamp - kt.Start_Timestamp) / 1e3
         piv = piv.join(kt.groupby("kernel").us.mean().rename("avg_us"))
     if out.endswith(".md"):   # machine-readable twin for bench.py's roofline.traffic
