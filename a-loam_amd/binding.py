@@ -48,7 +48,7 @@ def build(force: bool = False) -> str:
     srcs = [os.path.join(src_dir, f) for f in os.listdir(src_dir)] + [HEADER_PATH]
     stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if stale:
-        r = subprocess.run(["make", "-C", src_dir], capture_output=True, text=True)
+        r = subprocess.run(["make", "-j4", "-C", src_dir], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc build failed:\n" + r.stdout + r.stderr)
     return LIB_PATH

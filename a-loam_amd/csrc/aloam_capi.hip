@@ -26,6 +26,7 @@ const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_classify", "k_ring_offset
                                      "k_solve", "k_advance", "map_begin", "map_voxel[stacks]", "map_grid", "map_associate", "map_solve",
                                      "map_insert", "map_voxel[cubes]", "map_register"};
 struct ProfRec { int kernel; hipEvent_t e0, e1; };
+constexpr int kNinSlots = 8;
 }  // namespace
 
 struct aloam_ctx {
@@ -36,7 +37,9 @@ struct aloam_ctx {
   // input staging (host-input path only)
   char* d_in = nullptr; size_t d_in_bytes = 0;
   char* h_pin = nullptr; size_t h_pin_bytes = 0;
-  int* d_nin = nullptr; std::vector<int> h_nin;   // pageable on purpose: the async H2D copy stages it before returning
+  int* d_nin = nullptr;
+  int* h_nin = nullptr; int h_nin_slot = 0;         // pinned ring of kNinSlots x B counts: an async H2D copy reads its slot later
+  hipEvent_t nin_done[8] = {}; bool nin_used[8] = {};
   SeqMeta* d_meta = nullptr;
   int8_t* d_ringid = nullptr; float* d_ori = nullptr;
   int *d_hist = nullptr, *d_blockoff = nullptr, *d_ringstart = nullptr;
@@ -191,9 +194,15 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   for (int b = 0; b < c->B; ++b) {
     if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
     if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
-    c->h_nin[b] = n_in[b];
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_nin, c->h_nin.data(), sizeof(int) * c->B, hipMemcpyHostToDevice, c->stream));
+  const int ns = c->h_nin_slot;
+  c->h_nin_slot = (ns + 1) % kNinSlots;
+  int* slot = c->h_nin + (size_t)ns * c->B;
+  if (c->nin_used[ns]) HIP_TRY(c, hipEventSynchronize(c->nin_done[ns]));   // the copy queued kNinSlots launches ago has read it
+  std::memcpy(slot, n_in, sizeof(int) * c->B);
+  HIP_TRY(c, hipMemcpyAsync(c->d_nin, slot, sizeof(int) * c->B, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->nin_done[ns], c->stream));
+  c->nin_used[ns] = true;
   const RegArgs a = reg_args(c, d_scans, seq_stride, stride_bytes);
   { ProfScope p(c, K_FIND_ENDS); launch_find_ends(a, c->d_nin, c->stream); }
   { ProfScope p(c, K_CLASSIFY); launch_classify(a, c->stream); }
@@ -230,7 +239,7 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
   c->cfg = *cfg;
   *out = c;   // returned even on failure so that aloam_last_error() works; caller destroys it
   if (cfg->batch < 1 || cfg->max_points < 32 || cfg->max_points > 400000 || cfg->lm_max_iterations < 0 || cfg->outer_iterations < 1 ||
-      cfg->outer_iterations > 2) { c->err = "bad configuration value"; return ALOAM_E_ARG; }
+      cfg->outer_iterations > 64) { c->err = "bad configuration value"; return ALOAM_E_ARG; }
   if (!cfg->ring_from_field && cfg->n_scans != 16 && cfg->n_scans != 32 && cfg->n_scans != 64) {
     c->err = "only support velodyne with 16, 32 or 64 scan line (or ring_from_field)";   // src/scanRegistration.cpp:472-476
     return ALOAM_E_SCAN_LINES;
@@ -239,14 +248,16 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
   if (cfg->max_ring_points < 17 || cfg->max_ring_points > 4107) { c->err = "max_ring_points must be in [17, 4107]"; return ALOAM_E_ARG; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { c->err = "no HIP device available (this library has no CPU fallback)"; return ALOAM_E_HIP; }
-  HIP_TRY(c, hipSetDevice(cfg->device));
+  if (cfg->device < 0 || cfg->device >= ndev) { c->err = "device ordinal out of range"; return ALOAM_E_ARG; }
+  DeviceScope device_scope(c);                      // the caller's current device is restored on every return path
   HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   c->B = cfg->batch; c->cap = cfg->max_points; c->R = cfg->n_scans;
   c->NB = (c->cap + kBlockPts - 1) / kBlockPts;
   c->npad = cfg->max_ring_points <= 2059 ? 2048 : 4096;
   const size_t B = c->B, cap = c->cap, R = c->R, NB = c->NB;
   int rc = 0;
-  c->h_nin.assign(B, 0);
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_nin, sizeof(int) * B * kNinSlots, hipHostMallocDefault));
+  for (hipEvent_t& e : c->nin_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   if ((rc = dmalloc(c, &c->d_nin, B))) return rc;
   if ((rc = dmalloc(c, &c->d_meta, B))) return rc;
   if ((rc = dmalloc(c, &c->d_ringid, B * cap))) return rc;
@@ -310,6 +321,8 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
+  if (c->h_nin) (void)hipHostFree(c->h_nin);
+  for (hipEvent_t e : c->nin_done) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -351,7 +364,7 @@ int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in,
   const size_t seq_stride = (size_t)c->cap * stride_bytes;
   const size_t need = seq_stride * c->B;
   if (c->d_in_bytes < need) {
-    if (c->d_in) HIP_TRY(c, hipFree(c->d_in));
+    if (c->d_in) { char* old = c->d_in; c->d_in = nullptr; c->d_in_bytes = 0; HIP_TRY(c, hipFree(old)); }
     HIP_TRY(c, hipMalloc((void**)&c->d_in, need));
     c->d_in_bytes = need;
   }

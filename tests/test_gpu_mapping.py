@@ -140,7 +140,7 @@ def test_full_pipeline_registration_odometry_mapping(O, binding, sequence, name,
 
 def test_full_size_mapping_batch(O, binding, syn):
     """BASELINE configs[2] size: HDL-64, 131072 points per sweep, registration -> odometry -> mapping for a batch through the
-    device-resident entry point.  Sequence 0 against the oracle; size-independent properties for every sequence: the submap seen
+    device-resident entry point.  Every sequence against its own oracle run; size-independent properties for every sequence: the submap seen
     by frame k is the map left by frame k-1, every down-sampled stack point lands in exactly one cube before the re-filter
     (point-count conservation), the refined trajectory stays within a few centimetres of the synthetic ground truth."""
     import torch
@@ -162,22 +162,24 @@ def test_full_size_mapping_batch(O, binding, syn):
     torch.cuda.synchronize()
     gpu = binding.Aloam(n_scans=64, min_range=model.min_range, batch=B, max_points=NP, max_ring_points=2059)
     gpu.mapping_enable(0.4, 0.8, pool_points=262144)
-    orc = O.Oracle(n_scans=64, min_range=model.min_range)
-    orc.map_config(0.4, 0.8)
-    host0 = data[0].cpu().numpy()
+    orcs = [O.Oracle(n_scans=64, min_range=model.min_range) for _ in range(B)]
+    for orc in orcs:
+        orc.map_config(0.4, 0.8)
+    host = data.cpu().numpy()
     prev_total = [0] * B
     for k in range(T):
         gpu.process_device(data.data_ptr() + k * NP * 16, T * NP * 16, counts[:, k])
         gpu.mapping_step()
         gpu.synchronize()
-        orc.scan_register(host0[k, :counts[0, k]])
-        po = orc.odometry_step()
-        pm = orc.mapping_step(po["q_w"], po["t_w"], orc.cloud(O.CLOUD_CORNER_LAST), orc.cloud(O.CLOUD_SURF_LAST), orc.cloud(O.CLOUD_FULL))
-        mg = gpu.map_pose(0)
-        for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
-            assert np.abs(pm[key] - mg[key]).max() < 1e-8, (k, key)
-        for cls in (0, 1):
-            _compare_maps(gpu.map_cubes(cls, 0), orc.map_cubes(cls), (k, cls), exact=False)
+        for b, orc in enumerate(orcs):                                      # every sequence against its own oracle run
+            orc.scan_register(host[b, k, :counts[b, k]])
+            po = orc.odometry_step()
+            pm = orc.mapping_step(po["q_w"], po["t_w"], orc.cloud(O.CLOUD_CORNER_LAST), orc.cloud(O.CLOUD_SURF_LAST), orc.cloud(O.CLOUD_FULL))
+            mg = gpu.map_pose(b)
+            for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+                assert np.abs(pm[key] - mg[key]).max() < 1e-8, (b, k, key)
+            for cls in (0, 1):
+                _compare_maps(gpu.map_cubes(cls, b), orc.map_cubes(cls), (b, k, cls), exact=False)
         for b in range(B):
             info = gpu.map_info(b)
             total = sum(len(v) for v in gpu.map_cubes(0, b).values()) + sum(len(v) for v in gpu.map_cubes(1, b).values())

@@ -197,7 +197,7 @@ def test_gpu_reproduces_committed_goldens(binding, path):
 
 def test_full_size_batch_properties(O, binding, syn):
     """BASELINE size (HDL-64, 131072 points per sweep) in a batch of 8 through the device-resident entry point:
-    size-independent properties + one sequence checked against the oracle."""
+    size-independent properties + every sequence checked against its own oracle run."""
     import torch
     B, T = 8, 3
     dev = torch.device("cuda", 0)
@@ -268,7 +268,6 @@ def test_distortion_mode_matches_oracle(O, binding, sequence):
     gpu.close()
 
 
-@pytest.mark.xfail(strict=False, reason="written after this round's GPU budget was spent: never run on hardware yet; promote to a plain test once it has passed")
 @pytest.mark.parametrize("mode", ["unsorted", "far"])
 def test_last_clouds_that_are_not_ring_sorted_or_out_of_range(O, binding, sequence, mode):
     """aloam_set_last accepts any cloud.  'unsorted': ring keys not ascending -> the literal walk loops (:312-361 / :402-455)
@@ -307,7 +306,6 @@ def test_last_clouds_that_are_not_ring_sorted_or_out_of_range(O, binding, sequen
     gpu.close()
 
 
-@pytest.mark.xfail(strict=False, reason="written after this round's GPU budget was spent: never run on hardware yet; promote to a plain test once it has passed")
 @pytest.mark.parametrize("outer,lm", [(1, 4), (3, 2), (2, 8), (2, 0)])
 def test_solver_settings_other_than_the_reference_defaults(O, binding, sequence, outer, lm):
     """opti_counter loop (src/laserOdometry.cpp:278) and options.max_num_iterations (:496) are configuration here; the

@@ -38,6 +38,32 @@ def main():
         print(path, os.path.getsize(path) // 1024, "KiB")
 
 
+DISTORT_CASES = [("refdistort_hdl64_c256_seed15", "HDL-64", 5, 15, {"columns": 256}), ("refdistort_vlp16_c600_seed16", "VLP-16", 5, 16, {"columns": 600})]
+
+
+def main_distortion():
+    """The de-skew branch of the reference's odometry node (src/laserOdometry.cpp:115-118,376-377,474-475), which ships compiled
+    out by `#define DISTORTION 0` (:59): oracle/_ref/ref_laser_odometry_distort is the same translation unit with that one define
+    flipped on its way into the compiler (oracle/Makefile).  Registration by the reference's scanRegistration.cpp as usual."""
+    exe = os.path.join(ref_py.REF_DIR, "ref_laser_odometry_distort")
+    for tag, name, frames, seed, kw in DISTORT_CASES:
+        scans, R, t, model = syn.make_sequence(name, frames, seed=seed, **kw)
+        xs = [s.numpy() for s in scans]
+        reg = ref_py.scan_registration(xs, model.n_scans, model.min_range)
+        odo = ref_py.laser_odometry(reg, exe=exe)
+        plain = ref_py.laser_odometry(reg)
+        out = {"R": R.numpy(), "t": t.numpy(), "n_scans": model.n_scans, "min_range": model.min_range, "frames": frames}
+        for k in range(frames):
+            out[f"scan{k}"] = xs[k]
+            for key in ("q_lc", "t_lc", "q_w", "t_w"):
+                out[f"{key}{k}"] = odo[k][key]
+                out[f"plain_{key}{k}"] = plain[k][key]          # DISTORTION 0 on the same sweeps: shows the branch does something
+            out[f"corr{k}"] = np.array([odo[k]["corner_corr"], odo[k]["plane_corr"]])
+        path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path) // 1024, "KiB")
+
+
 MAP_CASES = [("refmap_hdl64_c256_seed13", "HDL-64", 6, 13, {"columns": 256}, 0.4, 0.8), ("refmap_vlp16_c600_seed14", "VLP-16", 6, 14, {"columns": 600}, 0.2, 0.4)]
 
 
@@ -94,3 +120,4 @@ if __name__ == "__main__":
     main()
     main_mapping()
     main_factors()
+    main_distortion()
