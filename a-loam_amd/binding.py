@@ -87,6 +87,9 @@ def lib():
         L.aloam_synchronize.argtypes = [vp]
         L.aloam_scan_register.argtypes = [vp, C.POINTER(vp), ip, C.c_int]
         L.aloam_scan_register_device.argtypes = [vp, vp, C.c_longlong, ip, C.c_int]
+        L.aloam_scan_register_host.argtypes = [vp, vp, C.c_longlong, ip, C.c_int]
+        L.aloam_process_host.argtypes = [vp, vp, C.c_longlong, ip, C.c_int]
+        L.aloam_input_consumed.argtypes = [vp]
         L.aloam_odometry_step.argtypes = [vp]
         L.aloam_process_device.argtypes = [vp, vp, C.c_longlong, ip, C.c_int]
         L.aloam_cloud_size.argtypes = [vp, C.c_int, C.c_int]
@@ -191,6 +194,18 @@ class Aloam:
     def process_device(self, d_ptr, seq_stride_bytes, n_in, stride_bytes=16):
         nin = n_in if isinstance(n_in, C.Array) else (C.c_int * self.batch)(*[int(v) for v in n_in])
         self._check(lib().aloam_process_device(self.h, C.c_void_p(d_ptr), seq_stride_bytes, nin, stride_bytes))
+
+    def process_host(self, h_ptr, seq_stride_bytes, n_in, stride_bytes=16):
+        """One host-resident batch (pinned for true asynchrony): batched H2D copy on the copy stream + stage 1 + stage 2."""
+        nin = n_in if isinstance(n_in, C.Array) else (C.c_int * self.batch)(*[int(v) for v in n_in])
+        self._check(lib().aloam_process_host(self.h, C.c_void_p(h_ptr), seq_stride_bytes, nin, stride_bytes))
+
+    def scan_register_host(self, h_ptr, seq_stride_bytes, n_in, stride_bytes=16):
+        nin = n_in if isinstance(n_in, C.Array) else (C.c_int * self.batch)(*[int(v) for v in n_in])
+        self._check(lib().aloam_scan_register_host(self.h, C.c_void_p(h_ptr), seq_stride_bytes, nin, stride_bytes))
+
+    def input_consumed(self):
+        self._check(lib().aloam_input_consumed(self.h))
 
     def synchronize(self):
         self._check(lib().aloam_synchronize(self.h))

@@ -35,8 +35,12 @@ struct aloam_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   // input staging (host-input path only)
-  char* d_in = nullptr; size_t d_in_bytes = 0;
-  char* h_pin = nullptr; size_t h_pin_bytes = 0;
+  // two device slabs: the H2D copy of call k + 1 (copy stream) overlaps the kernels of call k (compute stream)
+  char* d_in[2] = {nullptr, nullptr}; size_t d_in_bytes[2] = {0, 0};
+  int in_slot = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t in_copied[2] = {}, in_consumed[2] = {}; bool in_used[2] = {false, false};
+  char* h_pin = nullptr; size_t h_pin_bytes = 0;    // pinned bounce buffer for pageable callers of aloam_scan_register
   int* d_nin = nullptr;
   int* h_nin = nullptr; int h_nin_slot = 0;         // pinned ring of kNinSlots x B counts: an async H2D copy reads its slot later
   hipEvent_t nin_done[8] = {}; bool nin_used[8] = {};
@@ -189,7 +193,7 @@ int fetch_meta(aloam_ctx* c, int seq, SeqMeta* m) {
   return ALOAM_OK;
 }
 
-int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, const int* n_in, int stride_bytes) {
+int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, const int* n_in, int stride_bytes, int slot = -1) {
   if (stride_bytes < 16 || (stride_bytes & 3)) { c->err = "stride_bytes must be >= 16 and a multiple of 4"; return ALOAM_E_ARG; }
   for (int b = 0; b < c->B; ++b) {
     if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
@@ -197,10 +201,10 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   }
   const int ns = c->h_nin_slot;
   c->h_nin_slot = (ns + 1) % kNinSlots;
-  int* slot = c->h_nin + (size_t)ns * c->B;
+  int* nin_slot = c->h_nin + (size_t)ns * c->B;
   if (c->nin_used[ns]) HIP_TRY(c, hipEventSynchronize(c->nin_done[ns]));   // the copy queued kNinSlots launches ago has read it
-  std::memcpy(slot, n_in, sizeof(int) * c->B);
-  HIP_TRY(c, hipMemcpyAsync(c->d_nin, slot, sizeof(int) * c->B, hipMemcpyHostToDevice, c->stream));
+  std::memcpy(nin_slot, n_in, sizeof(int) * c->B);
+  HIP_TRY(c, hipMemcpyAsync(c->d_nin, nin_slot, sizeof(int) * c->B, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->nin_done[ns], c->stream));
   c->nin_used[ns] = true;
   const RegArgs a = reg_args(c, d_scans, seq_stride, stride_bytes);
@@ -208,6 +212,7 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   { ProfScope p(c, K_CLASSIFY); launch_classify(a, c->stream); }
   { ProfScope p(c, K_RING_OFFSETS); launch_ring_offsets(a, c->stream); }
   { ProfScope p(c, K_SCATTER); launch_scatter(a, c->stream); }
+  if (slot >= 0) { HIP_TRY(c, hipEventRecord(c->in_consumed[slot], c->stream)); c->in_used[slot] = true; }   // the raw sweep is not read after this
   { ProfScope p(c, K_RING_FEATURES); launch_ring_features(a, c->npad, 0.2f, c->stream); }   // leaf 0.2 (src/scanRegistration.cpp:404)
   { ProfScope p(c, K_COMPACT); launch_compact_features(a, c->stream); }
   HIP_TRY(c, hipGetLastError());
@@ -251,6 +256,11 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
   if (cfg->device < 0 || cfg->device >= ndev) { c->err = "device ordinal out of range"; return ALOAM_E_ARG; }
   DeviceScope device_scope(c);                      // the caller's current device is restored on every return path
   HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k) {
+    HIP_TRY(c, hipEventCreateWithFlags(&c->in_copied[k], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->in_consumed[k], hipEventDisableTiming));
+  }
   c->B = cfg->batch; c->cap = cfg->max_points; c->R = cfg->n_scans;
   c->NB = (c->cap + kBlockPts - 1) / kBlockPts;
   c->npad = cfg->max_ring_points <= 2059 ? 2048 : 4096;
@@ -308,7 +318,8 @@ void aloam_destroy(aloam_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   prof_resolve(c);
   for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
-  void* bufs[] = {c->d_in, c->d_nin, c->d_meta, c->d_ringid, c->d_ori, c->d_hist, c->d_blockoff, c->d_ringstart, c->d_cloud, c->d_curv,
+  if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+  void* bufs[] = {c->d_in[0], c->d_in[1], c->d_nin, c->d_meta, c->d_ringid, c->d_ori, c->d_hist, c->d_blockoff, c->d_ringstart, c->d_cloud, c->d_curv,
                   c->d_label, c->d_sharp_idx, c->d_less_sharp_idx, c->d_flat_idx, c->d_pick_cnt, c->d_lf_ring, c->d_lf_cnt, c->d_sharp,
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
@@ -323,6 +334,8 @@ void aloam_destroy(aloam_ctx* c) {
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_nin) (void)hipHostFree(c->h_nin);
   for (hipEvent_t e : c->nin_done) if (e) (void)hipEventDestroy(e);
+  for (int k = 0; k < 2; ++k) { if (c->in_copied[k]) (void)hipEventDestroy(c->in_copied[k]); if (c->in_consumed[k]) (void)hipEventDestroy(c->in_consumed[k]); }
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -357,24 +370,85 @@ int aloam_scan_register_device(aloam_ctx* c, const void* d_scans, long long seq_
   return register_launch(c, d_scans, seq_stride_bytes, n_in, stride_bytes);
 }
 
+// Next device staging slab for a host-resident batch: waits (host side) until the kernels that read the slab two calls ago
+// are done with it, grows it if needed.
+static int acquire_slab(aloam_ctx* c, size_t need, int* slot_out) {
+  const int s = c->in_slot;
+  c->in_slot ^= 1;
+  if (c->in_used[s]) HIP_TRY(c, hipEventSynchronize(c->in_consumed[s]));
+  if (c->d_in_bytes[s] < need) {
+    if (c->d_in[s]) { char* old = c->d_in[s]; c->d_in[s] = nullptr; c->d_in_bytes[s] = 0; HIP_TRY(c, hipFree(old)); }
+    HIP_TRY(c, hipMalloc((void**)&c->d_in[s], need));
+    c->d_in_bytes[s] = need;
+  }
+  *slot_out = s;
+  return ALOAM_OK;
+}
+
 int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in, int stride_bytes) {
   DeviceScope device_scope(c);
   if (!c || !scans || !n_in) return ALOAM_E_ARG;
   if (stride_bytes < 16) { c->err = "stride_bytes must be >= 16"; return ALOAM_E_ARG; }
   const size_t seq_stride = (size_t)c->cap * stride_bytes;
-  const size_t need = seq_stride * c->B;
-  if (c->d_in_bytes < need) {
-    if (c->d_in) { char* old = c->d_in; c->d_in = nullptr; c->d_in_bytes = 0; HIP_TRY(c, hipFree(old)); }
-    HIP_TRY(c, hipMalloc((void**)&c->d_in, need));
-    c->d_in_bytes = need;
-  }
-  for (int b = 0; b < c->B; ++b) {
-    if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
-    if (n_in[b] > 0) HIP_TRY(c, hipMemcpyAsync(c->d_in + b * seq_stride, scans[b], (size_t)n_in[b] * stride_bytes, hipMemcpyHostToDevice, c->stream));
-  }
-  const int rc = register_launch(c, c->d_in, (long long)seq_stride, n_in, stride_bytes);
+  for (int b = 0; b < c->B; ++b) if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
+  int slot = 0;
+  int rc = acquire_slab(c, seq_stride * c->B, &slot);
+  if (rc) return rc;
+  for (int b = 0; b < c->B; ++b)
+    if (n_in[b] > 0) HIP_TRY(c, hipMemcpyAsync(c->d_in[slot] + b * seq_stride, scans[b], (size_t)n_in[b] * stride_bytes, hipMemcpyHostToDevice, c->stream));
+  rc = register_launch(c, c->d_in[slot], (long long)seq_stride, n_in, stride_bytes, slot);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));   // the host buffers may be reused on return
+  return ALOAM_OK;
+}
+
+// Host-resident batch in ONE buffer (sequence b at h_scans + b * seq_stride_bytes): one batched H2D copy on the context's copy
+// stream into the next of two device slabs, the kernels wait for it on the compute stream — so the copy of call k + 1 runs
+// under the kernels of call k.  Truly asynchronous only from pinned memory (hipHostMalloc / hipHostRegister); the runtime stages
+// pageable memory synchronously.  The buffer must stay unmodified until aloam_input_consumed() / aloam_synchronize().
+static int stage_and_register(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
+  if (!c || !h_scans || !n_in) return ALOAM_E_ARG;
+  if (stride_bytes < 16 || (stride_bytes & 3) || seq_stride_bytes < 0) { c->err = "bad stride"; return ALOAM_E_ARG; }
+  int nmax = 0;
+  for (int b = 0; b < c->B; ++b) {
+    if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
+    if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
+    nmax = std::max(nmax, n_in[b]);
+  }
+  const size_t d_seq_stride = (size_t)c->cap * stride_bytes;
+  int slot = 0;
+  int rc = acquire_slab(c, d_seq_stride * c->B, &slot);
+  if (rc) return rc;
+  const size_t row = (size_t)nmax * stride_bytes;
+  if (c->B > 1 && (size_t)seq_stride_bytes < row) { c->err = "seq_stride_bytes smaller than a scan"; return ALOAM_E_ARG; }
+  if (row > 0) {
+    if (c->B == 1) {
+      HIP_TRY(c, hipMemcpyAsync(c->d_in[slot], h_scans, row, hipMemcpyHostToDevice, c->copy_stream));
+    } else {
+      HIP_TRY(c, hipMemcpy2DAsync(c->d_in[slot], d_seq_stride, h_scans, (size_t)seq_stride_bytes, row, (size_t)c->B, hipMemcpyHostToDevice, c->copy_stream));
+    }
+  }
+  HIP_TRY(c, hipEventRecord(c->in_copied[slot], c->copy_stream));
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_copied[slot], 0));
+  return register_launch(c, c->d_in[slot], (long long)d_seq_stride, n_in, stride_bytes, slot);
+}
+
+int aloam_scan_register_host(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
+  DeviceScope device_scope(c);
+  return stage_and_register(c, h_scans, seq_stride_bytes, n_in, stride_bytes);
+}
+
+int aloam_process_host(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
+  DeviceScope device_scope(c);
+  const int rc = stage_and_register(c, h_scans, seq_stride_bytes, n_in, stride_bytes);
+  if (rc) return rc;
+  return aloam_odometry_step(c);
+}
+
+int aloam_input_consumed(aloam_ctx* c) {
+  DeviceScope device_scope(c);
+  if (!c) return ALOAM_E_ARG;
+  for (int s = 0; s < 2; ++s) if (c->in_used[s]) HIP_TRY(c, hipEventSynchronize(c->in_consumed[s]));
   return ALOAM_OK;
 }
 
@@ -630,6 +704,8 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
     // per-launch algorithmic traffic from the sizes of the LAST sweep (DESIGN.md "Algorithmic bytes")
     std::vector<SeqMeta> m(c->B);
     HIP_TRY(c, hipMemcpy(m.data(), c->d_meta, sizeof(SeqMeta) * c->B, hipMemcpyDeviceToHost));
+    std::vector<MapSeq> ms(c->map_on ? c->B : 0);
+    if (c->map_on) HIP_TRY(c, hipMemcpy(ms.data(), c->d_mapseq, sizeof(MapSeq) * c->B, hipMemcpyDeviceToHost));
     double bytes = 0;
     for (int b = 0; b < c->B; ++b) {
       const double Nin = m[b].n_in, N = m[b].n_cloud, Fc = m[b].n_sharp, Lc = m[b].n_less_sharp, Fs = m[b].n_flat, Ls = m[b].n_less_flat;
@@ -647,9 +723,23 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
         case K_SOLVE: bytes += 9.0 * (48 * Fc + 64 * Fs); break;
         // mapping: incoming clouds read + stacks written; submap read + grid written; queries + 5 neighbours + records;
         // 9 evaluations of the records; stacks -> cubes; valid cubes read + written; full cloud in + out
-        case K_MAP_VOXEL_STACK: bytes += 16 * (Lcl + Lsl) + 24 * (Lcl + Lsl); break;
-        case K_MAP_REGISTER: bytes += 32 * N; break;
         default: break;
+      }
+      if (c->map_on && kernel >= K_MAP_BEGIN) {
+        // scan-to-map stages, from the sizes of the last frame: S = down-sampled stacks, M = submap, F = factors
+        const double Sc = ms[b].n_stack[0], Ss = ms[b].n_stack[1], Mc = ms[b].from_total[0], Ms = ms[b].from_total[1];
+        const double Fc = ms[b].factor_num[1][0], Fs = ms[b].factor_num[1][1];
+        switch (kernel) {
+          case K_MAP_BEGIN: bytes += 2.0 * kMapValidMax * sizeof(CubeDesc) + sizeof(MapSeq); break;           // window descriptors + state
+          case K_MAP_VOXEL_STACK: bytes += 16 * (Lcl + Lsl) + 16 * (Sc + Ss); break;                          // incoming clouds in, stacks out
+          case K_MAP_GRID: bytes += 32 * (Mc + Ms) + 8.0 * (c->map_H[0] + c->map_H[1]); break;               // submap in, bucketed copy + tables out
+          case K_MAP_ASSOC: bytes += 16 * (Sc + Ss) + 80 * (Sc + Ss) + sizeof(MapEdgeRec) * Sc + sizeof(MapNormRec) * Ss; break;   // query + 5 neighbours in, record out
+          case K_MAP_SOLVE: bytes += 9.0 * (sizeof(MapEdgeRec) * Fc + sizeof(MapNormRec) * Fs); break;        // <= 5 Jacobian + 4 cost evaluations
+          case K_MAP_INSERT: bytes += 32 * (Sc + Ss); break;                                                  // stacks in, cube appends out
+          case K_MAP_VOXEL_CUBES: bytes += 32 * (Mc + Ms + Sc + Ss); break;                                   // valid cubes re-filtered in place
+          case K_MAP_REGISTER: bytes += 32 * N; break;                                                        // full cloud in + out
+          default: break;
+        }
       }
     }
     *algorithmic_bytes = bytes;

@@ -3,20 +3,27 @@
 
 One "step" = one sweep of every one of `--batch` independent sequences per GPU pushed through
 aloam_process_device(): stage 1 (reference src/scanRegistration.cpp:127-411) + stage 2 (reference
-src/laserOdometry.cpp:265-506,554-568).  Workload = BASELINE.json configs[1] with synthetic data (KITTI is not in
-the image): 64 rings x 2048 columns = 131072 points per sweep, ring-major like KITTI .bin files, minimum_range 5,
+src/laserOdometry.cpp:265-506,554-568).  Headline workload = BASELINE.json configs[1] with synthetic data (KITTI is
+not in the image): 64 rings x 2048 columns = 131072 points per sweep, ring-major like KITTI .bin files, minimum_range 5,
 noise sigma 0.02 m, sensor driven 1 m per sweep on a 30 m circle.  Inputs are resident in HBM before the timed
 region; every sequence replays its `--frames` stored sweeps forwards and backwards (consecutive sweeps are always
 1 m apart, so the odometry problem is the real one at every step).
 
-Multi-GPU (--gpus N under torch.distributed.run): sequences are independent, each rank owns `--batch` of them, no
-data-path collective; a barrier brackets the timed region and the max time over ranks is used ("scaling": "weak").
+Multi-GPU: `python bench.py --gpus N` starts N ranks itself (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* exported, rendezvous on 127.0.0.1); under `python -m torch.distributed.run ... bench.py --gpus N` the ranks already
+exist and are used as they are.  Sequences are independent, each rank owns `--batch` of them, there is no data-path
+collective; a barrier brackets the timed region and the max time over ranks is used ("scaling": "weak").
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with the extra objects
-  roofline     - dominant kernel, algorithmic bytes per launch / its mean hipEvent duration, vs 8 TB/s HBM
-  cpu_baseline - the CPU oracle (oracle/, a restatement of the reference; "kind": "port") timed on one host core on
-                 the first sequence's sweeps, in the same run
-  accuracy     - per-sweep pose difference GPU vs oracle (parity) and trajectory ATE vs the synthetic ground truth
+Prints ONE JSON line on rank 0 (contract in the task statement).  Beside the headline (`value`) it carries, at N = 1:
+  roofline         - dominant kernel: algorithmic bytes per launch / its mean hipEvent duration, vs 8 TB/s HBM
+  value_host_input - the same steps fed from pinned HOST memory: one batched H2D copy per step on a copy stream, double-buffered
+                     against the kernels (aloam_process_host) — the PCIe-inclusive rate, never the headline
+  workloads        - BASELINE.json configs[2] (odometry + laserMapping refinement every sweep) and configs[3] (128 x 2048
+                     stress), each with its own ms_per_step / roofline
+  latency          - single-sensor (batch 1) milliseconds per sweep through the host-buffer entry points the ROS shims use
+  cpu_baseline     - the CPU oracle (oracle/, a restatement of the reference; "kind": "port"): one thread (median / p95 per
+                     sweep) and one process per host core (sequence-parallel), timed in the same run
+  accuracy         - per-sweep pose difference GPU vs oracle (parity) and trajectory ATE vs the synthetic ground truth
 """
 from __future__ import annotations
 
@@ -25,7 +32,10 @@ import ctypes
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,20 +44,16 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, p)
 
 import numpy as np
-import torch
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
+RK_NAMES = {"k_associate[plane]": "k_associate<true, false>", "k_associate[corner]": "k_associate<false, false>",
+            "k_ring_features": "k_ring_features<2048>", "k_solve": "k_solve<false>"}
 
 
 def quat_angle(qa, qb):
     """Rotation angle between two xyzw quaternions."""
     d = abs(float(np.dot(qa, qb))) / (np.linalg.norm(qa) * np.linalg.norm(qb))
     return 2.0 * float(np.arccos(min(1.0, d)))
-
-
-def rot_to_quat(R):
-    from scipy.spatial.transform import Rotation
-    return Rotation.from_matrix(R).as_quat()
 
 
 def frame_order(n_frames, n_steps):
@@ -62,84 +68,102 @@ def frame_order(n_frames, n_steps):
     return out
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="independent sequences per GPU")
     ap.add_argument("--frames", type=int, default=6, help="stored sweeps per sequence (replayed ping-pong)")
-    ap.add_argument("--sensor", default="HDL-64")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mapping", action="store_true", help="BASELINE configs[2]: also run the scan-to-map refinement every sweep")
+    ap.add_argument("--sensor", default="HDL-64", help="headline workload sensor (HDL-64 = BASELINE configs[1]; ROWS128 = configs[3])")
+    ap.add_argument("--mapping", action="store_true", help="headline workload = BASELINE configs[2]: scan-to-map refinement after every sweep")
     ap.add_argument("--map-pool", type=int, default=262144, help="device map capacity per sequence and class (points)")
-    ap.add_argument("--contexts", type=int, default=1, help="split the batch over this many contexts (= HIP streams) on the same GPU so that "
-                    "kernels with different bottlenecks overlap")
-    ap.add_argument("--host-input", action="store_true", help="feed the sweeps from host memory through aloam_scan_register (PCIe-inclusive rate; "
-                    "reported as value_host_input next to the HBM-resident value, never instead of it)")
-    args = ap.parse_args()
+    ap.add_argument("--contexts", type=int, default=1, help="split the batch over this many contexts (= HIP streams) on the same GPU")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU baseline leg (one thread; one process per core)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip host-input rate, configs[2]/[3] sub-workloads and latency")
+    ap.add_argument("--host-input", action="store_true", help="(kept for compatibility: the host-fed rate is part of the default line)")
+    ap.add_argument("--latency-sweeps", type=int, default=120)
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
 
-    binding = importlib.import_module("a-loam_amd.binding")
-    syn = importlib.import_module("a-loam_amd.synthetic")
-    if not os.path.exists(binding.LIB_PATH):
-        binding.build()
+# ---------------------------------------------------------------------------------------------------------------------
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU)."""
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count()
+    assert have >= n, f"--gpus {n} but only {have} HIP device(s) are visible"
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    sys.exit(rc)
 
-    B, T = args.batch, args.frames
-    model = syn.sensor_model(args.sensor, device=dev)
-    NP = model.dirs.shape[0]
-    # ---- synthetic input, generated on the GPU, resident in HBM: [B][T][NP][4] float32 ----
-    t_gen = time.time()
-    data = torch.zeros((B, T, NP, 4), dtype=torch.float32, device=dev)
-    counts = np.zeros((B, T), np.int32)
-    worlds = [syn.make_world(100 + w).to(dev) for w in range(8)]
-    gt = {}
-    for b in range(B):
-        gseq = rank * B + b
-        R, tt = syn.trajectory(T, step=1.0, seed=gseq, start_angle=0.37 * gseq)
-        gen = torch.Generator(device=dev).manual_seed(9000 + gseq)
-        for k in range(T):
-            s = syn.render_scan(worlds[gseq % len(worlds)], model, R[k], tt[k], 0.02, gen)
-            counts[b, k] = s.shape[0]
-            data[b, k, : s.shape[0]] = s
-        if b < 4:
-            gt[b] = (R.numpy(), tt.numpy())
-    torch.cuda.synchronize()
-    t_gen = time.time() - t_gen
 
-    NC = max(1, args.contexts)
-    assert B % NC == 0, "--batch must be a multiple of --contexts"
-    BC = B // NC
-    ctxs = [binding.Aloam(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field, batch=BC,
-                          max_points=NP, max_ring_points=2059 if model.columns <= 2048 else 4107, device=local_rank) for _ in range(NC)]
-    ctx = ctxs[0]
-    if args.mapping:
-        for c in ctxs:
-            c.mapping_enable(0.4, 0.8, args.map_pool)      # launch/aloam_velodyne_HDL_64.launch: mapping_line / plane_resolution
-    seq_stride = T * NP * 16
-    order = frame_order(T, args.warmup + args.steps)
-    nin = {(k, c): (ctypes.c_int * BC)(*[int(v) for v in counts[c * BC:(c + 1) * BC, k]]) for k in range(T) for c in range(NC)}
-    base = data.data_ptr()
+# ---------------------------------------------------------------------------------------------------------------------
+class Workload:
+    """Synthetic sweeps of B sequences x T frames, resident in HBM, and the bookkeeping to replay them."""
+
+    def __init__(self, syn, torch, sensor, B, T, rank, dev):
+        self.sensor, self.B, self.T = sensor, B, T
+        self.model = syn.sensor_model(sensor, device=dev)
+        self.NP = self.model.dirs.shape[0]
+        t0 = time.time()
+        self.data = torch.zeros((B, T, self.NP, 4), dtype=torch.float32, device=dev)
+        self.counts = np.zeros((B, T), np.int32)
+        worlds = [syn.make_world(100 + w).to(dev) for w in range(8)]
+        self.gt = {}
+        for b in range(B):
+            gseq = rank * B + b
+            R, tt = syn.trajectory(T, step=1.0, seed=gseq, start_angle=0.37 * gseq)
+            gen = torch.Generator(device=dev).manual_seed(9000 + gseq)
+            for k in range(T):
+                s = syn.render_scan(worlds[gseq % len(worlds)], self.model, R[k], tt[k], 0.02, gen)
+                self.counts[b, k] = s.shape[0]
+                self.data[b, k, : s.shape[0]] = s
+            if b < 4:
+                self.gt[b] = (R.numpy(), tt.numpy())
+        torch.cuda.synchronize()
+        self.gen_s = time.time() - t0
+        self.seq_stride = T * self.NP * 16
+
+    def ctx(self, binding, batch, device, **kw):
+        m = self.model
+        return binding.Aloam(n_scans=m.n_scans, min_range=m.min_range, ring_from_field=m.ring_from_field, batch=batch,
+                             max_points=self.NP, max_ring_points=2059 if m.columns <= 2048 else 4107, device=device, **kw)
+
+    def nin(self, k, lo=0, hi=None):
+        hi = self.B if hi is None else hi
+        return (ctypes.c_int * (hi - lo))(*[int(v) for v in self.counts[lo:hi, k]])
+
+    def describe(self, mapping):
+        m = self.model
+        return f"synthetic {self.sensor} {m.n_scans}x{m.columns} ({self.NP} pts/sweep), " + (
+            "odometry + laserMapping scan-to-map refinement every sweep" if mapping else "odometry only (scan registration + scan-to-scan odometry, no laserMapping)")
+
+
+def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping):
+    """W untimed + exactly K timed steps with the inputs resident in HBM; per-kernel hipEvents on the context's own stream."""
+    NC, BC = len(ctxs), wl.B // len(ctxs)
+    order = frame_order(wl.T, warmup + steps)
+    nin = {(k, c): wl.nin(k, c * BC, (c + 1) * BC) for k in range(wl.T) for c in range(NC)}
+    base = wl.data.data_ptr()
 
     def step(k):
         for c, cx in enumerate(ctxs):                      # asynchronous launches: the contexts' streams run concurrently
-            cx.process_device(base + c * BC * seq_stride + k * NP * 16, seq_stride, nin[(k, c)])
-            if args.mapping:
+            cx.process_device(base + c * BC * wl.seq_stride + k * wl.NP * 16, wl.seq_stride, nin[(k, c)])
+            if mapping:
                 cx.mapping_step()
 
-    for k in order[: args.warmup]:
+    for k in order[:warmup]:
         step(k)
     for cx in ctxs:
         cx.synchronize()
@@ -147,9 +171,9 @@ def main():
     if world > 1:
         dist.barrier()
     if NC == 1:
-        ctx.profile_enable(True)                           # per-kernel hipEvents serialise nothing on one stream; with several
+        ctxs[0].profile_enable(True)                       # per-kernel hipEvents serialise nothing on one stream; with several
     t0 = time.perf_counter()                               # streams they would only measure overlapped intervals, so they stay off
-    for k in order[args.warmup:]:
+    for k in order[warmup:]:
         step(k)
     for cx in ctxs:
         cx.synchronize()
@@ -157,123 +181,253 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=wl.data.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if NC > 1:                                             # per-kernel profile from one extra, untimed pass on a single context
-        ctx.profile_enable(True)
-        for k in order[args.warmup:]:
-            ctx.process_device(base + k * NP * 16, seq_stride, nin[(k, 0)])
-            if args.mapping:
-                ctx.mapping_step()
-        ctx.synchronize()
-    prof = ctx.profile()
-    ctx.profile_enable(False)
+        ctxs[0].profile_enable(True)
+        for k in order[warmup:]:
+            ctxs[0].process_device(base + k * wl.NP * 16, wl.seq_stride, nin[(k, 0)])
+            if mapping:
+                ctxs[0].mapping_step()
+        ctxs[0].synchronize()
+    prof = ctxs[0].profile()
+    ctxs[0].profile_enable(False)
+    return elapsed, prof
 
-    host_rate = None
-    if args.host_input:                                    # same steps, inputs handed over as host buffers (one H2D copy per sweep)
-        host = data.cpu().numpy()
-        hctx = binding.Aloam(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field, batch=B,
-                             max_points=NP, max_ring_points=2059 if model.columns <= 2048 else 4107, device=local_rank)
-        def hstep(k):
-            hctx.scan_register([host[b, k, : counts[b, k]] for b in range(B)], check=False)
-            hctx.odometry_step()
-        for k in order[: args.warmup]:
-            hstep(k)
-        hctx.synchronize()
-        th = time.perf_counter()
-        for k in order[args.warmup:]:
-            hstep(k)
-        hctx.synchronize()
-        host_rate = B * args.steps / (time.perf_counter() - th)
-        hctx.close()
 
-    total_scans = world * B * args.steps
-    value = total_scans / elapsed
-
-    # ---- roofline object for the dominant kernel ----
-    dom = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-    dname, d = dom
+def roofline_of(prof, steps, B, sensor, mapping):
+    """Roofline object of the dominant kernel (by accumulated hipEvent time)."""
+    dname, d = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
     avg_ms = d["total_ms"] / max(1, d["launches"])
     achieved = d["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"kernel": dname, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_launch": d["bytes_per_launch"],
-                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 4) for k, v in prof.items()}}
-
-    # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes of THIS command (tools/gpu_round.sh;
+    step_bytes = sum(v["bytes_per_launch"] * v["launches"] for v in prof.values()) / max(1, steps)
+    step_ms = sum(v["total_ms"] for v in prof.values()) / max(1, steps)
+    r = {"kernel": dname, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+         "algorithmic_bytes_per_launch": d["bytes_per_launch"],
+         "whole_step": {"algorithmic_bytes": step_bytes, "kernel_ms": round(step_ms, 4),
+                        "achieved_gbs": round(step_bytes / (step_ms * 1e-3) / 1e9, 2) if step_ms > 0 else 0.0,
+                        "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if step_ms > 0 else 0.0},
+         "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in prof.items() if v["launches"]}}
+    # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes of THIS command (tools/gpu_pmc.sh;
     # MI355X_MICROARCH.md: counters in their own passes; FETCH_SIZE [KiB] reports half the bytes of wide coalesced reads on
     # gfx950 -> doubled; WRITE_SIZE [KiB] as reported).  Only attached when the profiled configuration is this one.
+    for name in ("pmc_traffic_latest.json", "pmc_traffic_mapping.json", "pmc_traffic_rows128.json"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if pm.get("batch") == B and pm.get("mapping") == bool(mapping) and pm.get("sensor") == sensor:
+            cands = [k for k in pm.get("fetch_kib", {}) if k == RK_NAMES.get(dname, dname) or k.split("<")[0] == dname]
+            if cands and cands[0] in pm.get("write_kib", {}):
+                r["traffic"] = round((2.0 * pm["fetch_kib"][cands[0]] + pm["write_kib"][cands[0]]) * 1024.0)
+                r["traffic_source"] = pm.get("source", "profiles/")
+            break
+    return r
+
+
+def host_fed(torch, binding, wl, local_rank, steps, warmup, mapping=False):
+    """The same steps with every sweep crossing PCIe: the batch sits in PINNED host memory, each step is one batched H2D copy on
+    the context's copy stream into one of two device slabs, overlapped with the previous step's kernels."""
+    host = wl.data.cpu().pin_memory()
+    cx = wl.ctx(binding, wl.B, local_rank)
+    order = frame_order(wl.T, warmup + steps)
+    nin = {k: wl.nin(k) for k in range(wl.T)}
+    hp = host.data_ptr()
+    for k in order[:warmup]:
+        cx.process_host(hp + k * wl.NP * 16, wl.seq_stride, nin[k])
+    cx.synchronize()
+    t0 = time.perf_counter()
+    for k in order[warmup:]:
+        cx.process_host(hp + k * wl.NP * 16, wl.seq_stride, nin[k])
+    cx.synchronize()
+    el = time.perf_counter() - t0
+    cx.close()
+    bytes_per_step = float(sum(int(wl.counts[:, k].max()) for k in order[warmup:])) / steps * 16 * wl.B
+    del host
+    return {"value": round(wl.B * steps / el, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el / steps, 4),
+            "pcie_gbs": round(bytes_per_step / (el / steps) / 1e9, 2),
+            "how": "pinned host batch, one hipMemcpy2DAsync per step on a copy stream, two device slabs (copy of step k+1 under the kernels of step k), aloam_process_host"}
+
+
+def latency(binding, wl, local_rank, sweeps, mapping):
+    """Single sensor (batch 1), host buffers, blocking calls: what a drop-in ROS node gets per sweep."""
+    host = [wl.data[0, k, : wl.counts[0, k]].cpu().numpy() for k in range(wl.T)]
+    cx = wl.ctx(binding, 1, local_rank)
+    if mapping:
+        cx.mapping_enable(0.4, 0.8, 262144)
+    order = frame_order(wl.T, sweeps + 5)
+    reg, odo, mp = [], [], []
+    for i, k in enumerate(order):
+        t0 = time.perf_counter()
+        cx.scan_register(host[k], check=False)            # blocks until the host buffer may be reused
+        t1 = time.perf_counter()
+        cx.odometry_step()
+        cx.synchronize()
+        t2 = time.perf_counter()
+        if mapping:
+            cx.mapping_step()
+            cx.synchronize()
+        t3 = time.perf_counter()
+        if i >= 5:
+            reg.append(t1 - t0); odo.append(t2 - t1); mp.append(t3 - t2)
+    cx.close()
+    tot = np.array(reg) + np.array(odo) + np.array(mp)
+    q = lambda v, p: round(1e3 * float(np.percentile(v, p)), 3)
+    out = {"sweeps": len(reg), "unit": "ms per sweep", "scan_registration_median": q(reg, 50), "scan_registration_p95": q(reg, 95),
+           "odometry_median": q(odo, 50), "odometry_p95": q(odo, 95), "total_median": q(tot, 50), "total_p95": q(tot, 95),
+           "reference_budget_ms_per_stage": 100, "how": "batch 1, pageable host sweep -> aloam_scan_register + aloam_odometry_step + aloam_synchronize per sweep"}
+    if mapping:
+        out["mapping_median"], out["mapping_p95"] = q(mp, 50), q(mp, 95)
+    return out
+
+
+def cpu_baseline(args, wl, rank):
+    """The oracle on the host cores: one thread (per-sweep median / p95), then one process per core (sequence-parallel)."""
+    m = wl.model
+    order = frame_order(wl.T, 2 * wl.T - 1)
+    tmp = tempfile.mkdtemp(prefix="aloam_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(tmp, "sweeps.npz")
+    host = wl.data[0].cpu().numpy()
+    np.savez(path, T=wl.T, order=np.array(order), n_scans=m.n_scans, min_range=m.min_range, ring_from_field=int(m.ring_from_field),
+             line_res=0.4, plane_res=0.8, **{f"s{k}": host[k, : wl.counts[0, k]] for k in range(wl.T)})
+    worker = [sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), path, str(args.cpu_seconds)]
+    one = json.loads(subprocess.run(worker, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    per = np.array(one["per_scan_ms"][1:])                 # the first sweep of a sequence has no odometry solve
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen(worker, stdout=subprocess.PIPE, text=True) for _ in range(cores)]
+    outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+    wall = time.perf_counter() - t0
+    rate_all = sum(o["scans"] / o["seconds"] for o in outs)
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")))
-        if pm.get("batch") == B and pm.get("mapping") == bool(args.mapping) and pm.get("sensor") == args.sensor:
-            rk = {"k_associate[plane]": "k_associate<true, false>", "k_associate[corner]": "k_associate<false, false>", "k_ring_features": "k_ring_features<2048>",
-                  "k_solve": "k_solve<false>"}.get(dname, dname)
-            if rk not in pm["fetch_kib"]:
-                rk = rk.replace(", false>", ">").replace("<false>", "")          # names of builds before the de-skew template parameter
-            if rk in pm["fetch_kib"] and rk in pm["write_kib"]:
-                roofline["traffic"] = round((2.0 * pm["fetch_kib"][rk] + pm["write_kib"][rk]) * 1024.0)
-                roofline["traffic_source"] = pm.get("source", "profiles/")
-    except (OSError, ValueError, KeyError):
+        for f in os.listdir(tmp):
+            os.remove(os.path.join(tmp, f))
+        os.rmdir(tmp)
+    except OSError:
         pass
+    return {"value": round(one["scans"] / one["seconds"], 3), "unit": "scans/s", "cores": 1, "kind": "port",
+            "ms_per_scan_median": round(float(np.median(per)), 3), "ms_per_scan_p95": round(float(np.percentile(per, 95)), 3),
+            "sample": f"{one['scans']} sweeps of one synthetic {wl.sensor} sequence ({args.cpu_seconds:.0f} s), oracle/ (kd-tree NN, dual-number autodiff, dense QR LM), 1 thread",
+            "all_cores": {"value": round(rate_all, 2), "unit": "scans/s", "cores": cores, "kind": "port",
+                          "sample": f"{cores} processes x {args.cpu_seconds:.0f} s, one independent sequence per core (same sweeps), {sum(o['scans'] for o in outs)} sweeps, wall {wall:.1f} s"}}
+
+
+def accuracy(binding, wl, local_rank, mapping=False):
+    import oracle_py
+    n_seq = min(2, wl.B)
+    order = frame_order(wl.T, 2 * wl.T - 1)
+    acc = wl.ctx(binding, n_seq, local_rank)
+    gpu_poses = [[] for _ in range(n_seq)]
+    base = wl.data.data_ptr()
+    for k in order:
+        acc.process_device(base + k * wl.NP * 16, wl.seq_stride, [int(v) for v in wl.counts[:n_seq, k]])
+        for b in range(n_seq):
+            gpu_poses[b].append(acc.pose(b))
+    acc.close()
+    host = wl.data[:n_seq].cpu().numpy()
+    m = wl.model
+    max_dt = max_drot = ate_sq = ate_o_sq = 0.0
+    ate_n = 0
+    for b in range(n_seq):
+        orc = oracle_py.Oracle(n_scans=m.n_scans, min_range=m.min_range, ring_from_field=m.ring_from_field)
+        Rg, tg = wl.gt[b]
+        for i, k in enumerate(order):
+            orc.scan_register(host[b, k, : wl.counts[b, k]])
+            po = orc.odometry_step()
+            pg = gpu_poses[b][i]
+            max_dt = max(max_dt, float(np.abs(po["t_lc"] - pg["t_lc"]).max()), float(np.linalg.norm(po["t_w"] - pg["t_w"])))
+            max_drot = max(max_drot, quat_angle(po["q_lc"], pg["q_lc"]), quat_angle(po["q_w"], pg["q_w"]))
+            if i < wl.T:   # forward part: compare with ground truth expressed in the first frame
+                t_gt = Rg[0].T @ (tg[k] - tg[0])
+                ate_sq += float(np.sum((pg["t_w"] - t_gt) ** 2)); ate_o_sq += float(np.sum((po["t_w"] - t_gt) ** 2)); ate_n += 1
+    return {"gpu_vs_oracle_max_dt_m": max_dt, "gpu_vs_oracle_max_drot_rad": max_drot, "sweeps_compared": len(order) * n_seq,
+            "ate_gpu_vs_gt_m": (ate_sq / max(1, ate_n)) ** 0.5, "ate_oracle_vs_gt_m": (ate_o_sq / max(1, ate_n)) ** 0.5,
+            "tolerance": "1e-4 m / 1e-4 rad (BASELINE.json north_star)"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    assert torch.cuda.device_count() > local_rank, f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} device(s) visible"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # control plane only: barrier + MAX of the elapsed time
+
+    binding = importlib.import_module("a-loam_amd.binding")
+    syn = importlib.import_module("a-loam_amd.synthetic")
+    if not os.path.exists(binding.LIB_PATH):
+        binding.build()
+
+    B, T = args.batch, args.frames
+    wl = Workload(syn, torch, args.sensor, B, T, rank, dev)
+    NC = max(1, args.contexts)
+    assert B % NC == 0, "--batch must be a multiple of --contexts"
+    ctxs = [wl.ctx(binding, B // NC, local_rank) for _ in range(NC)]
+    if args.mapping:
+        for c in ctxs:
+            c.mapping_enable(0.4, 0.8, args.map_pool)      # launch/aloam_velodyne_HDL_64.launch: mapping_line / plane_resolution
+    elapsed, prof = timed_resident(torch, dist, world, ctxs, wl, args.steps, args.warmup, args.mapping)
+    for cx in ctxs:
+        cx.close()
+    value = world * B * args.steps / elapsed
 
     out = {"metric": "HDL-64 scans/sec (whole node)", "value": round(value, 2), "unit": "scans/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",
-           "config": {"workload": f"synthetic {args.sensor} {model.n_scans}x{model.columns} ({NP} pts/sweep), " + ("odometry + laserMapping scan-to-map refinement every sweep" if args.mapping else "odometry only (scan registration + scan-to-scan odometry, no laserMapping)"),
-                      "sequences_per_gpu": B, "contexts_per_gpu": NC, "stored_frames": T, "points_per_sweep": NP, "parallelism": f"{world} x independent sequence shards, no collectives"},
-           "roofline": roofline, "input_generation_s": round(t_gen, 2)}
-    if host_rate is not None:
-        out["value_host_input"] = round(host_rate, 2)      # per rank, PCIe-inclusive, pageable host buffers
+           "config": {"workload": wl.describe(args.mapping), "sequences_per_gpu": B, "contexts_per_gpu": NC, "stored_frames": T,
+                      "points_per_sweep": wl.NP, "parallelism": f"{world} x independent sequence shards, no collectives"},
+           "roofline": roofline_of(prof, args.steps, B, args.sensor, args.mapping), "input_generation_s": round(wl.gen_s, 2)}
 
-    # ---- CPU baseline + accuracy (rank 0, N = 1 only) ----
+    extras = rank == 0 and world == 1 and not args.no_extras
+    if extras:
+        hf = host_fed(torch, binding, wl, local_rank, args.steps, args.warmup)
+        out["value_host_input"] = hf["value"]              # per GPU, PCIe-inclusive; never the headline
+        out["host_input"] = hf
+        out["latency"] = latency(binding, wl, local_rank, args.latency_sweeps, mapping=False)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle_py
-        n_acc_seq = min(2, B)
-        acc_order = frame_order(T, 2 * T - 1)
-        acc = binding.Aloam(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field, batch=n_acc_seq,
-                            max_points=NP, max_ring_points=2059 if model.columns <= 2048 else 4107, device=local_rank)
-        gpu_poses = [[] for _ in range(n_acc_seq)]
-        for k in acc_order:
-            acc.process_device(base + k * NP * 16, seq_stride, [int(v) for v in counts[:n_acc_seq, k]])
-            for b in range(n_acc_seq):
-                gpu_poses[b].append(acc.pose(b))
-        acc.close()
-        host = data[:n_acc_seq].cpu().numpy()
-        cpu_t, cpu_scans = 0.0, 0
-        max_dt, max_drot, ate_sq, ate_n, ate_o_sq = 0.0, 0.0, 0.0, 0, 0.0
-        for b in range(n_acc_seq):
-            orc = oracle_py.Oracle(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field)
-            Rg, tg = gt[b]
-            for i, k in enumerate(acc_order):
-                x = host[b, k, : counts[b, k]]
-                t1 = time.perf_counter()
-                orc.scan_register(x)
-                po = orc.odometry_step()
-                cpu_t += time.perf_counter() - t1
-                cpu_scans += 1
-                pg = gpu_poses[b][i]
-                max_dt = max(max_dt, float(np.abs(po["t_lc"] - pg["t_lc"]).max()), float(np.linalg.norm(po["t_w"] - pg["t_w"])))
-                max_drot = max(max_drot, quat_angle(po["q_lc"], pg["q_lc"]), quat_angle(po["q_w"], pg["q_w"]))
-                if i < T:   # forward part: compare with ground truth expressed in the first frame
-                    t_gt = Rg[0].T @ (tg[k] - tg[0])
-                    ate_sq += float(np.sum((pg["t_w"] - t_gt) ** 2)); ate_o_sq += float(np.sum((po["t_w"] - t_gt) ** 2)); ate_n += 1
-            if cpu_t > args.cpu_seconds and b + 1 < n_acc_seq:
-                break
-        # keep timing the oracle on further sweeps until the budget is used
-        orc = oracle_py.Oracle(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field)
-        i = 0
-        while cpu_t < args.cpu_seconds:
-            k = acc_order[i % len(acc_order)]; i += 1
-            x = host[0, k, : counts[0, k]]
-            t1 = time.perf_counter(); orc.scan_register(x); orc.odometry_step(); cpu_t += time.perf_counter() - t1; cpu_scans += 1
-        out["cpu_baseline"] = {"value": round(cpu_scans / cpu_t, 3), "unit": "scans/s", "cores": 1, "kind": "port",
-                               "sample": f"{cpu_scans} sweeps of the same synthetic {args.sensor} sequences, oracle/ (kd-tree NN, dual-number autodiff, dense QR LM), 1 thread, host cores available: {os.cpu_count()}"}
-        out["accuracy"] = {"gpu_vs_oracle_max_dt_m": max_dt, "gpu_vs_oracle_max_drot_rad": max_drot, "sweeps_compared": len(acc_order) * n_acc_seq,
-                           "ate_gpu_vs_gt_m": (ate_sq / max(1, ate_n)) ** 0.5, "ate_oracle_vs_gt_m": (ate_o_sq / max(1, ate_n)) ** 0.5,
-                           "tolerance": "1e-4 m / 1e-4 rad (BASELINE.json north_star)"}
-    for cx in ctxs:
+        out["accuracy"] = accuracy(binding, wl, local_rank)
+        out["cpu_baseline"] = cpu_baseline(args, wl, rank)
+    if extras and not args.mapping and args.sensor == "HDL-64":
+        # ---- BASELINE.json configs[2]: the same sweeps with the scan-to-map refinement after every sweep
+        steps2, warm2 = max(4, args.steps // 2), args.warmup
+        cx = wl.ctx(binding, B, local_rank)
+        cx.mapping_enable(0.4, 0.8, args.map_pool)
+        el2, prof2 = timed_resident(torch, dist, 1, [cx], wl, steps2, warm2, True)
+        info = cx.map_info(0)
         cx.close()
+        lat_map = latency(binding, wl, local_rank, max(30, args.latency_sweeps // 3), mapping=True)
+        out["workloads"] = {"configs[2] odometry + laserMapping": {
+            "workload": wl.describe(True), "value": round(B * steps2 / el2, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el2 / steps2, 4),
+            "steps": steps2, "warmup": warm2, "sequences_per_gpu": B, "map_pool_points": args.map_pool,
+            "roofline": roofline_of(prof2, steps2, B, "HDL-64", True), "map_state_seq0": {k: info[k] for k in ("frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack")},
+            "latency": lat_map}}
+        del wl
+        torch.cuda.empty_cache()
+        # ---- BASELINE.json configs[3]: 128 rings x 2048 columns stress (ring index from the 4th float)
+        T3 = min(T, 4)
+        wl3 = Workload(syn, torch, "ROWS128", B, T3, rank, dev)
+        cx = wl3.ctx(binding, B, local_rank)
+        el3, prof3 = timed_resident(torch, dist, 1, [cx], wl3, steps2, warm2, False)
+        cx.close()
+        out["workloads"]["configs[3] 128x2048 stress"] = {
+            "workload": wl3.describe(False), "value": round(B * steps2 / el3, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el3 / steps2, 4),
+            "steps": steps2, "warmup": warm2, "sequences_per_gpu": B, "points_per_sweep": wl3.NP,
+            "roofline": roofline_of(prof3, steps2, B, "ROWS128", False), "input_generation_s": round(wl3.gen_s, 2)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -89,11 +89,20 @@ int aloam_scan_register(aloam_ctx* ctx, const void* const* scans, const int* n_i
 /* Device-resident input: sequence b starts at d_scans + b * seq_stride_bytes.  Fully asynchronous.           */
 int aloam_scan_register_device(aloam_ctx* ctx, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes);
 
+/* Host-resident batch in ONE buffer (sequence b at h_scans + b * seq_stride_bytes): what a driver thread that receives the
+ * sensor messages (reference src/scanRegistration.cpp:114-133) hands over.  One batched H2D copy per call on a dedicated copy
+ * stream into one of two device slabs, so the copy of call k + 1 runs under the kernels of call k; asynchronous when the buffer is
+ * pinned (hipHostMalloc / hipHostRegister).  The buffer must stay unmodified until aloam_input_consumed() or aloam_synchronize(). */
+int aloam_scan_register_host(aloam_ctx* ctx, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes);
+int aloam_input_consumed(aloam_ctx* ctx);                            /* waits until every host buffer handed over so far has been copied and read */
+
 /* ---- stage 2: odometry main-loop body (reference src/laserOdometry.cpp:265-506,554-568) -------------------- */
 int aloam_odometry_step(aloam_ctx* ctx);                             /* asynchronous; all sequences             */
 
 /* ---- throughput entry: stage 1 + stage 2 for one sweep of every sequence, asynchronous -------------------- */
 int aloam_process_device(aloam_ctx* ctx, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes);
+
+int aloam_process_host(aloam_ctx* ctx, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes);   /* same from a host buffer (see aloam_scan_register_host) */
 
 /* ---- stage 3: scan-to-map refinement, body of process() (reference src/laserMapping.cpp:231-893), no frame dropping ---- */
 /* Replaces the node's globals (cube arrays laserCloudCornerArray / SurfArray[4851], q_wmap_wodom, t_wmap_wodom, `parameters`,

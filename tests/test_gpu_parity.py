@@ -322,3 +322,50 @@ def test_solver_settings_other_than_the_reference_defaults(O, binding, sequence,
         for key in ("corner_corr", "plane_corr", "lm_iterations", "lm_successful", "termination"):
             assert so_[key] == sg_[key], (outer, lm, k, key, so_, sg_)
     gpu.close()
+
+
+def test_host_batch_entry_is_double_buffered_and_matches_device_entry(O, binding, syn):
+    """aloam_process_host (one pinned host buffer for the whole batch, batched H2D copy on the copy stream, two device slabs) over
+    several back-to-back asynchronous steps == aloam_process_device on the same sweeps, bit for bit, and == the oracle."""
+    import torch
+    B, T = 3, 5
+    dev = torch.device("cuda", 0)
+    model = syn.sensor_model("HDL-64", columns=512, device=dev)
+    NP = model.dirs.shape[0]
+    data = torch.zeros((B, T, NP, 4), dtype=torch.float32, device=dev)
+    counts = np.zeros((B, T), np.int32)
+    world = syn.make_world(77).to(dev)
+    for b in range(B):
+        R, t = syn.trajectory(T, seed=90 + b, start_angle=0.3 * b)
+        gen = torch.Generator(device=dev).manual_seed(90 + b)
+        for k in range(T):
+            s = syn.render_scan(world, model, R[k], t[k], 0.02, gen)
+            counts[b, k] = len(s); data[b, k, :len(s)] = s
+    host = data.cpu().pin_memory()
+    g_dev = _mk(binding, model, batch=B, max_points=NP, max_ring_points=2059)
+    g_host = _mk(binding, model, batch=B, max_points=NP, max_ring_points=2059)
+    for k in range(T):                                                     # no synchronisation in between: the slabs alternate
+        g_host.process_host(host.data_ptr() + k * NP * 16, T * NP * 16, counts[:, k])
+        g_dev.process_device(data.data_ptr() + k * NP * 16, T * NP * 16, counts[:, k])
+    g_host.input_consumed()
+    g_host.synchronize(); g_dev.synchronize()
+    orcs = [O.Oracle(n_scans=64, min_range=model.min_range) for _ in range(B)]
+    hn = host.numpy()
+    for b in range(B):
+        for k in range(T):
+            orcs[b].scan_register(hn[b, k, :counts[b, k]])
+            po = orcs[b].odometry_step()
+        ph, pd = g_host.pose(b), g_dev.pose(b)
+        for key in ("q_w", "t_w", "q_lc", "t_lc"):
+            assert np.array_equal(ph[key], pd[key]), (b, key)
+        _assert_pose_close(po, ph, b)
+        assert bits_equal(g_host.cloud(binding.CLOUD_SURF_LAST, b), g_dev.cloud(binding.CLOUD_SURF_LAST, b))
+        assert bits_equal(orcs[b].cloud(O.CLOUD_SURF_LAST), g_host.cloud(binding.CLOUD_SURF_LAST, b))
+    # a pageable single-sequence buffer through the same entry (the runtime stages it synchronously)
+    g1 = _mk(binding, model, batch=1, max_points=NP, max_ring_points=2059)
+    x = np.ascontiguousarray(hn[0, 0, :counts[0, 0]])
+    g1.scan_register_host(x.ctypes.data, 0, [len(x)])
+    g1.synchronize()
+    o1 = O.Oracle(n_scans=64, min_range=model.min_range)
+    _assert_features_equal(o1.scan_register(x), g1.features(), "pageable host")
+    g1.close(); g_host.close(); g_dev.close()
