@@ -18,11 +18,11 @@
 using namespace aloam;
 
 namespace {
-enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_COMPACT, K_BUILD_GRIDS, K_ASSOC_CORNER,
+enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_COMPACT, K_BUILD_GRIDS, K_TRANSFORM, K_ASSOC_CORNER,
                 K_ASSOC_PLANE, K_SOLVE, K_ADVANCE, K_MAP_BEGIN, K_MAP_VOXEL_STACK, K_MAP_GRID, K_MAP_ASSOC, K_MAP_SOLVE, K_MAP_INSERT,
                 K_MAP_VOXEL_CUBES, K_MAP_REGISTER, K_COUNT };
 const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_classify", "k_ring_offsets", "k_scatter", "k_ring_features",
-                                     "k_compact_features", "k_build_grids", "k_associate[corner]", "k_associate[plane]",
+                                     "k_compact_features", "k_build_grids", "k_transform_queries", "k_associate[corner]", "k_associate[plane]",
                                      "k_solve", "k_advance", "map_begin", "map_voxel[stacks]", "map_grid", "map_associate", "map_solve",
                                      "map_insert", "map_voxel[cubes]", "map_register"};
 struct ProfRec { int kernel; hipEvent_t e0, e1; };
@@ -63,6 +63,7 @@ struct aloam_ctx {
   int grid_H[2] = {4096, 16384};
   bool grids_valid = false;          // the grids describe the current "last" clouds
   EdgeRec* d_edges = nullptr; PlaneRec* d_planes = nullptr;
+  float4 *d_sel_sharp = nullptr, *d_sel_flat = nullptr;
   // scan-to-map refinement (allocated by aloam_mapping_enable)
   bool map_on = false;
   float map_line_res = 0.4f, map_plane_res = 0.8f;
@@ -171,6 +172,7 @@ OdomArgs odom_args(aloam_ctx* c) {
   }
   a.grid_H_corner = c->grid_H[0]; a.grid_H_surf = c->grid_H[1];
   a.edges = c->d_edges; a.planes = c->d_planes;
+  a.sel_sharp = c->d_sel_sharp; a.sel_flat = c->d_sel_flat;
   a.lm_max_iterations = c->cfg.lm_max_iterations;
   a.distortion = c->cfg.distortion != 0;
   return a;
@@ -303,6 +305,8 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
   }
   if ((rc = dmalloc(c, &c->d_edges, B * R * 12))) return rc;
   if ((rc = dmalloc(c, &c->d_planes, B * R * 24))) return rc;
+  if ((rc = dmalloc(c, &c->d_sel_sharp, B * R * 12))) return rc;
+  if ((rc = dmalloc(c, &c->d_sel_flat, B * R * 24))) return rc;
   // identity poses (src/laserOdometry.cpp:93-98)
   std::vector<OdomState> init(B);
   std::memset(init.data(), 0, sizeof(OdomState) * B);
@@ -321,7 +325,7 @@ void aloam_destroy(aloam_ctx* c) {
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   void* bufs[] = {c->d_in[0], c->d_in[1], c->d_nin, c->d_meta, c->d_ringid, c->d_ori, c->d_hist, c->d_blockoff, c->d_ringstart, c->d_cloud, c->d_curv,
                   c->d_label, c->d_sharp_idx, c->d_less_sharp_idx, c->d_flat_idx, c->d_pick_cnt, c->d_lf_ring, c->d_lf_cnt, c->d_sharp,
-                  c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes,
+                  c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes, c->d_sel_sharp, c->d_sel_flat,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
                   c->d_grid_start2[0], c->d_grid_start2[1],
                   c->d_grid_flags[0], c->d_grid_flags[1], c->d_grid_sorted3c[0], c->d_grid_sorted3c[1],
@@ -465,6 +469,7 @@ int aloam_odometry_step(aloam_ctx* c) {
     for (int outer = 0; outer < c->cfg.outer_iterations; ++outer) {
       a.outer = outer;
       a.last_outer = outer == c->cfg.outer_iterations - 1;
+      { ProfScope p(c, K_TRANSFORM); launch_transform_queries(a, c->stream); }    // TransformToStart of the features (:300, :388)
       { ProfScope p(c, K_ASSOC_CORNER); launch_associate(a, false, max_sharp, c->stream); }
       { ProfScope p(c, K_ASSOC_PLANE); launch_associate(a, true, max_flat, c->stream); }
       { ProfScope p(c, K_SOLVE); launch_solve(a, c->stream); }
@@ -718,6 +723,7 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
         case K_RING_FEATURES: bytes += 16 * N + 5 * N + 16 * Ls; break;
         case K_COMPACT: bytes += 32 * (Fc + Lc + Fs) + 32 * Ls; break;
         case K_BUILD_GRIDS: bytes += 16 * (Lcl + Lsl) + 48 * (Lcl + Lsl) + 12.0 * (c->grid_H[0] + c->grid_H[1]); break;   // read once, three sorted copies + three bucket tables out
+        case K_TRANSFORM: bytes += 32 * (Fc + Fs); break;
         case K_ASSOC_CORNER: bytes += 16 * (Fc + Lcl) + 48 * Fc; break;
         case K_ASSOC_PLANE: bytes += 16 * (Fs + Lsl) + 64 * Fs; break;
         case K_SOLVE: bytes += 9.0 * (48 * Fc + 64 * Fs); break;

@@ -92,6 +92,8 @@ struct OdomArgs {
   int* grid_start3c[2];      // [B][H+1]
   int* grid_flags[2];        // [B][4]   flags[0] != 0: keys / coordinates out of range -> literal brute-force path; flags[1] != 0: not ring-sorted -> literal walks
   int grid_H_corner, grid_H_surf;   // buckets (power of two, multiple of 1024)
+  float4* sel_sharp;         // [B][R*12]  features moved to the start of the sweep with the current pose (k_transform_queries)
+  float4* sel_flat;          // [B][R*24]
   EdgeRec* edges;            // [B][R*12]
   PlaneRec* planes;          // [B][R*24]
   int outer;                 // which outer iteration (0/1)
@@ -240,6 +242,34 @@ __device__ __forceinline__ unsigned long long wave_extreme_u64(unsigned long lon
   return best;                                                                // wave-uniform
 }
 
+// Wave-wide max / min of a 32-bit value: the same DPP ladder as the scans below (row_shr 1, 2, 4, 8, then row_bcast 15 / 31 carry the
+// row results upward); the compiler folds every step into one v_max/min_u32_dpp, lane 63 ends up with the result, one v_readlane
+// makes it wave-uniform.  7 VALU instructions instead of the ~35 of the xor-butterfly + four readlanes.
+template <bool MAX>
+__device__ __forceinline__ unsigned wave_reduce_u32(unsigned v) {
+  constexpr int identity = MAX ? 0 : -1;
+  auto op = [](unsigned a, unsigned b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(identity, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(identity, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(identity, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(identity, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(identity, (int)v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(identity, (int)v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Minimum of packed (high word = f32 distance bits, low word = tie-break) keys: reduce the high words; only when several lanes
+// hold the minimal high word (exactly equal f32 distances, or nobody holds a candidate at all) a second reduction settles the
+// low word.  Same value as the 64-bit reduction, a third of its instructions in the common case.
+__device__ __forceinline__ unsigned long long wave_min_packed(unsigned long long v) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = wave_reduce_u32<false>(hi);
+  const unsigned long long tie = __ballot(hi == mh);
+  unsigned ml;
+  if (__popcll(tie) == 1) ml = (unsigned)__builtin_amdgcn_readlane((int)lo, __ffsll((long long)tie) - 1);
+  else ml = wave_reduce_u32<false>(hi == mh ? lo : 0xffffffffu);
+  return ((unsigned long long)mh << 32) | ml;
+}
+
 // Inclusive wave64 scans on the DPP network (no LDS crossbar): Hillis-Steele inside each row of 16 lanes, then the row
 // totals travel with row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).  `identity` fills the lanes a shift
 // leaves without a source.
@@ -257,23 +287,25 @@ __device__ __forceinline__ int wave_scan_i32(int v) {
 }
 
 
-// LDS bitonic sort of n 64-bit keys, ascending, 256 threads.  The network is the all-ascending form (a "flip" stage
+// LDS bitonic sort of n 32- or 64-bit keys, ascending, 256 threads.  The network is the all-ascending form (a "flip" stage
 // i <-> block_end - i opens every merge, half-cleaners follow), so the slots n .. pow2ceil(n)-1 can stay imaginary +inf:
 // a pair whose upper partner lies beyond n is simply skipped, which removes a third of the LDS traffic at the typical
 // n ~ 0.7 * pow2ceil(n).  The stages that stay inside aligned groups of eight keys (the merges k = 2, 4 and 8, and the last
 // three half-cleaners of every later merge) run in registers: one read and one write of the group instead of one per stage.
 // Starts and ends with the data visible to the whole workgroup.
 __device__ __forceinline__ int pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
-__device__ __forceinline__ void bitonic_cx(unsigned long long& a, unsigned long long& b) {
-  const unsigned long long lo = a < b ? a : b, hi = a < b ? b : a;
+template <typename K>
+__device__ __forceinline__ void bitonic_cx(K& a, K& b) {
+  const K lo = a < b ? a : b, hi = a < b ? b : a;
   a = lo; b = hi;
 }
-template <bool FIRST>
-__device__ __forceinline__ void bitonic_groups_of_eight(unsigned long long* keys, int n, int tid) {
+template <bool FIRST, typename K>
+__device__ __forceinline__ void bitonic_groups_of_eight(K* keys, int n, int tid) {
+  constexpr K kInf = (K)~(K)0;
   for (int g = tid * 8; g < n; g += 2048) {
-    unsigned long long v[8];
+    K v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = g + u < n ? keys[g + u] : ~0ull;
+    for (int u = 0; u < 8; ++u) v[u] = g + u < n ? keys[g + u] : kInf;
     if (FIRST) {                                                             // merges k = 2, 4 and 8
 #pragma unroll
       for (int b = 0; b < 8; b += 2) bitonic_cx(v[b], v[b + 1]);
@@ -296,16 +328,17 @@ __device__ __forceinline__ void bitonic_groups_of_eight(unsigned long long* keys
   }
   __syncthreads();
 }
-__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n, int tid) {
+template <typename K>
+__device__ __forceinline__ void bitonic_sort_keys(K* keys, int n, int tid) {
   const int npad = pow2ceil(n);
-  bitonic_groups_of_eight<true>(keys, n, tid);
+  bitonic_groups_of_eight<true, K>(keys, n, tid);
   for (int k = 16; k <= npad; k <<= 1) {
     const int hk = k >> 1;
     for (int t = tid; t < (npad >> 1); t += 256) {                         // flip stage
       const int base = (t / hk) * k, off = t & (hk - 1);
       const int i = base + off, l = base + (k - 1 - off);
       if (l < n) {
-        const unsigned long long x = keys[i], y = keys[l];
+        const K x = keys[i], y = keys[l];
         if (x > y) { keys[i] = y; keys[l] = x; }
       }
     }
@@ -315,15 +348,16 @@ __device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         const int l = i + j;
         if (l < n) {
-          const unsigned long long x = keys[i], y = keys[l];
+          const K x = keys[i], y = keys[l];
           if (x > y) { keys[i] = y; keys[l] = x; }
         }
       }
       __syncthreads();
     }
-    bitonic_groups_of_eight<false>(keys, n, tid);
+    bitonic_groups_of_eight<false, K>(keys, n, tid);
   }
 }
+__device__ __forceinline__ void bitonic_sort_u64(unsigned long long* keys, int n, int tid) { bitonic_sort_keys<unsigned long long>(keys, n, tid); }
 
 
 }  // namespace aloam

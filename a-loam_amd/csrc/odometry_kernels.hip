@@ -240,8 +240,12 @@ __device__ __forceinline__ float walk_dist(const float4& p, const float4& sel) {
   return (p.x - sel.x) * (p.x - sel.x) + (p.y - sel.y) * (p.y - sel.y) + (p.z - sel.z) * (p.z - sel.z);
 }
 
+#ifndef ALOAM_ASSOC_MIN64
+#define ALOAM_ASSOC_MIN64 0     // A/B builds: 1 = the 64-bit xor-butterfly reduction of round 1
+#endif
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-  return wave_extreme_u64<false>(v, (int)(threadIdx.x & 63));               // DPP row reduction + 4 readlanes, no LDS crossbar
+  if (ALOAM_ASSOC_MIN64) return wave_extreme_u64<false>(v, (int)(threadIdx.x & 63));
+  return wave_min_packed(v);                                               // DPP ladder on the distance word, tie-break only on exact ties
 }
 
 // ---- shell enumeration -------------------------------------------------------------------------------------
@@ -399,6 +403,31 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
 }
 
 // -------------------------------------------------------------------------------------------------------
+// TransformToStart of every corner / planar feature of the current sweep with the current pose estimate (reference
+// src/laserOdometry.cpp:111-129, called at :300 and :388), one lane per feature, once per outer iteration.  The association
+// waves then load the transformed point instead of every one of their 64 lanes redoing the same f64 rotation.
+template <bool DISTORT>
+__global__ __launch_bounds__(256) void k_transform_queries(OdomArgs a) {
+  const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+  const SeqMeta m = a.meta[b];
+  if (i >= m.n_sharp + m.n_flat) return;
+  const bool plane = i >= m.n_sharp;
+  const int qi = plane ? i - m.n_sharp : i;
+  const long long o = plane ? (long long)b * a.R * 24 + qi : (long long)b * a.R * 12 + qi;
+  const float4 raw = plane ? a.flat[o] : a.sharp[o];
+  float4 sel;
+  if (DISTORT) {
+    const OdomState& st = a.state[b];
+    const double q[4] = {st.para_q[0], st.para_q[1], st.para_q[2], st.para_q[3]}, t[3] = {st.para_t[0], st.para_t[1], st.para_t[2]};
+    const float frac = raw.w - (float)(int)raw.w;                            // relTime of the point (:116)
+    double lp[3];
+    deskew_point(q, t, interpolation_ratio(frac), (double)raw.x, (double)raw.y, (double)raw.z, lp, nullptr);
+    sel = make_float4((float)lp[0], (float)lp[1], (float)lp[2], raw.w);
+  } else sel = transform_to_start(raw, a.state[b]);
+  (plane ? a.sel_flat : a.sel_sharp)[o] = sel;
+}
+
+// -------------------------------------------------------------------------------------------------------
 // Data association for one feature class, one wave per query (4 queries per workgroup):
 //   PLANE = false: corner features  (reference src/laserOdometry.cpp:299-384)  -> EdgeRec
 //   PLANE = true : planar features  (reference src/laserOdometry.cpp:387-483)  -> PlaneRec
@@ -407,8 +436,12 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
 // The kernel is a chain of dependent memory round trips per query (bucket bounds -> bucket entries, twice), so everything
 // that does not depend on a search result is loaded up front and nothing is fetched by index afterwards: grid entries
 // carry their ring key, and the lanes that saw the winners store the record fields themselves.
+#ifndef ALOAM_ASSOC_WAVES
+#define ALOAM_ASSOC_WAVES 1     // query waves per workgroup: measured 1: 1.47 ms, 2: 1.53, 4: 1.63, 8: 1.90 (planar class, batch 512) - single-wave groups refill freed SIMD slots soonest
+#endif
+constexpr int kAssocWaves = ALOAM_ASSOC_WAVES;
 template <bool PLANE, bool DISTORT>
-__global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
+__global__ __launch_bounds__(64 * kAssocWaves) void k_associate(OdomArgs a) {
   // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs by linear id and every XCD has its
   // own 4 MiB L2.  The grids of one sequence (~1.5 MB) are shared by all workgroups of that sequence, so the linear id
   // is re-mapped such that XCD x works through sequences x, x+8, x+16, ...: each L2 holds a few sequences' grids
@@ -417,24 +450,17 @@ __global__ __launch_bounds__(256) void k_associate(OdomArgs a) {
   const int b = (slot / (int)gridDim.x) * 8 + xcd, lane = threadIdx.x & 63;
   if (b >= a.B) return;
   constexpr int kSweep = PLANE ? 3 : 2;
-  __shared__ int s_row[4][kSweep * 64];
+  __shared__ int s_row[kAssocWaves][kSweep * 64];
   int* row = s_row[threadIdx.x >> 6];
-  const int qi = (slot % (int)gridDim.x) * 4 + (threadIdx.x >> 6);
+  const int qi = (slot % (int)gridDim.x) * kAssocWaves + (threadIdx.x >> 6);
   const int qcap = PLANE ? a.R * 24 : a.R * 12;
   const float4* Q = (PLANE ? a.flat : a.sharp) + (long long)b * qcap;
   const float4 raw = Q[qi < qcap ? qi : qcap - 1];                      // issued together with the scalar loads below
+  const float4 sel = ((PLANE ? a.sel_flat : a.sel_sharp) + (long long)b * qcap)[qi < qcap ? qi : qcap - 1];   // k_transform_queries
   const SeqMeta m = a.meta[b];
   const GridView g = grid_view(a, b, PLANE ? 1 : 0);
   const bool bad = g.flags[0] != 0, unsorted = g.flags[1] != 0;
   const float frac = raw.w - (float)(int)raw.w;                              // relTime of the point (:116)
-  float4 sel;
-  if (DISTORT) {
-    const OdomState& st = a.state[b];
-    const double q[4] = {st.para_q[0], st.para_q[1], st.para_q[2], st.para_q[3]}, t[3] = {st.para_t[0], st.para_t[1], st.para_t[2]};
-    double lp[3];
-    deskew_point(q, t, interpolation_ratio(frac), (double)raw.x, (double)raw.y, (double)raw.z, lp, nullptr);
-    sel = make_float4((float)lp[0], (float)lp[1], (float)lp[2], raw.w);
-  } else sel = transform_to_start(raw, a.state[b]);
   const int nq = PLANE ? m.n_flat : m.n_sharp;
   if (qi >= nq) return;
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
@@ -722,15 +748,20 @@ void launch_build_grids(const OdomArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL(k_build_grids, dim3(2, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
 }
+void launch_transform_queries(const OdomArgs& a, hipStream_t s) {
+  const dim3 grid((a.R * 36 + 255) / 256, a.B);
+  if (a.distortion) hipLaunchKernelGGL(k_transform_queries<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_transform_queries<false>, grid, dim3(256), 0, s, a);
+}
 void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
-  const dim3 grid((max_queries + 3) / 4, by);
+  const dim3 grid((max_queries + kAssocWaves - 1) / kAssocWaves, by), block(64 * kAssocWaves);
   if (a.distortion) {
-    if (plane) hipLaunchKernelGGL((k_associate<true, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_associate<false, true>), grid, dim3(256), 0, s, a);
+    if (plane) hipLaunchKernelGGL((k_associate<true, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_associate<false, true>), grid, block, 0, s, a);
   } else {
-    if (plane) hipLaunchKernelGGL((k_associate<true, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_associate<false, false>), grid, dim3(256), 0, s, a);
+    if (plane) hipLaunchKernelGGL((k_associate<true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_associate<false, false>), grid, block, 0, s, a);
   }
 }
 void launch_solve(const OdomArgs& a, hipStream_t s) {

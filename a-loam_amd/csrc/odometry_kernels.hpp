@@ -5,6 +5,7 @@
 namespace aloam {
 size_t build_grids_lds_bytes(int H, int R);
 void launch_build_grids(const OdomArgs& a, hipStream_t s);
+void launch_transform_queries(const OdomArgs& a, hipStream_t s);
 void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_t s);
 void launch_solve(const OdomArgs& a, hipStream_t s);
 void launch_advance(SeqMeta* meta, int B, hipStream_t s);

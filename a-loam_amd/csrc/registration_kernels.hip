@@ -17,6 +17,10 @@
 #include "aloam_device.hpp"
 #include "registration_kernels.hpp"
 
+#ifndef ALOAM_RF_STOP
+#define ALOAM_RF_STOP 0     // phase-timing builds only: k_ring_features returns after phase N (0 = the product)
+#endif
+
 namespace aloam {
 
 // -------------------------------------------------------------------------------------------------------
@@ -239,8 +243,15 @@ __global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
 
 // -------------------------------------------------------------------------------------------------------
 // wave-wide max / min of a 32-bit value: DPP inside the rows of 16, v_readlane across the four rows (wave-uniform result)
+#ifndef ALOAM_RF_KEYS64
+#define ALOAM_RF_KEYS64 0       // A/B builds: 1 = always 64-bit run keys (round 1)
+#endif
+#ifndef ALOAM_RF_BUTTERFLY
+#define ALOAM_RF_BUTTERFLY 0    // A/B builds: 1 = the xor-butterfly reduction of round 1
+#endif
 template <bool MAX>
 __device__ __forceinline__ unsigned wave_extreme_u32(unsigned v, int lane) {
+  if (!ALOAM_RF_BUTTERFLY) return wave_reduce_u32<MAX>(v);
   unsigned o;
   o = xor_lane_u32<1>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
   o = xor_lane_u32<2>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
@@ -341,6 +352,111 @@ __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, i
   if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
 }
 
+// ---- second half of pcl::VoxelGrid for one ring: run heads -> sort of the run keys -> voxel heads ->
+// centroids in input order.  K = key type (voxel index << SHIFT | first element of the run), see the call site.
+template <int NPAD, typename K, int SHIFT>
+__device__ __forceinline__ void voxel_runs_tail(unsigned char* smem, unsigned char* flags, const signed char* label, int* s_scan, int* s_misc,
+                                                const float4* cloud, float4* out, int L, int tid, int lane, int wave) {
+  const unsigned* vis = reinterpret_cast<const unsigned*>(smem);               // region A: voxel index per element [NPAD] ...
+  K* rkeys = reinterpret_cast<K*>(smem);                                      // ... replaced by the run keys once the heads are known
+  constexpr unsigned kEMask = SHIFT >= 32 ? 0xffffffffu : ((1u << (SHIFT & 31)) - 1u);
+  // run heads: a member whose predecessor is no member or sits in another voxel (members have label <= 0, never 0xffffffff).
+  // Elements are taken 256 at a time (element = it * 256 + tid: conflict-free LDS reads); the exclusive rank of a head in
+  // element order comes from wave ballots + a 4 x EIT table of wave counts — two barriers instead of a 16-barrier scan.
+  constexpr int EIT = NPAD / 256;
+  unsigned hmask = 0;                                                        // bit it: element it * 256 + tid starts a run
+  int hrank[EIT];
+  unsigned myvi[EIT];
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int e = it * 256 + tid;
+    bool h = false;
+    myvi[it] = 0xffffffffu;
+    if (e < L) {
+      const unsigned vi = vis[e];
+      const bool member = label[e + 5] <= 0;
+      h = member && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi);
+      myvi[it] = vi;
+      flags[e + 5] = (unsigned char)(member && !h);                          // the element continues the run of its predecessor
+    }
+    const unsigned long long m = __ballot(h);
+    hrank[it] = __popcll(m & ((1ull << lane) - 1ull));
+    if (h) hmask |= 1u << it;
+    if (lane == 0) s_scan[it * 4 + wave] = __popcll(m);
+  }
+  __syncthreads();
+  int n_runs = 0;
+  {
+    int run = 0;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int c = s_scan[it * 4 + w];
+        if (w == wave) hrank[it] += run;
+        run += c;
+      }
+    }
+    n_runs = run;
+  }
+#pragma unroll
+  for (int it = 0; it < EIT; ++it)
+    if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = (K)(((K)myvi[it] << SHIFT) | (K)e); }   // vis is dead: every thread read its share before the barrier
+  __syncthreads();
+  if (ALOAM_RF_STOP == 6) return;
+  bitonic_sort_keys<K>(rkeys, n_runs, tid);
+  if (ALOAM_RF_STOP == 7) return;
+
+  // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
+  unsigned vmask = 0;
+  int vrank[EIT];
+  __syncthreads();                                                           // s_scan is reused
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    const int p = it * 256 + tid;
+    const bool h = p < n_runs && (p == 0 || (unsigned)(rkeys[p - 1] >> SHIFT) != (unsigned)(rkeys[p] >> SHIFT));
+    const unsigned long long m = __ballot(h);
+    vrank[it] = __popcll(m & ((1ull << lane) - 1ull));
+    if (h) vmask |= 1u << it;
+    if (lane == 0) s_scan[it * 4 + wave] = __popcll(m);
+  }
+  __syncthreads();
+  {
+    int run = 0;
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const int c = s_scan[it * 4 + w];
+        if (w == wave) vrank[it] += run;
+        run += c;
+      }
+    }
+    if (tid == 0) s_misc[0] = run;                                           // number of occupied voxels = less-flat points of this ring
+  }
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) {
+    if (!((vmask >> it) & 1u)) continue;
+    const int p = it * 256 + tid;
+    const unsigned vi = (unsigned)(rkeys[p] >> SHIFT);
+    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+    int cnt = 0;
+    for (int q = p; q < n_runs; ++q) {                                       // the runs of this voxel, in element order
+      const K kq = rkeys[q];
+      if ((unsigned)(kq >> SHIFT) != vi) break;
+      int e = (int)((unsigned)kq & kEMask);
+      do {
+        const float4 pt = cloud[e + 5];
+        sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
+        ++cnt;
+        ++e;
+      } while (e < L && flags[e + 5]);                                        // the run stops at the next head or non-member
+    }
+    const float fc = (float)cnt;
+    out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+  }
+}
+
 template <int NPAD>
 __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int MAXN = NPAD + 11;
@@ -420,6 +536,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     __syncthreads();
   }
 
+  if (ALOAM_RF_STOP == 1) return;
   // reach of the neighbour suppression around every point: a pick of i marks i+1 .. i+fw and i-1 .. i-bk (runs of consecutive
   // gap-free steps, at most 5).  Packed into the flag byte: bit1 gap, bits 2-4 fw, bits 5-7 bk.
   unsigned char rb[ITEMS];
@@ -443,12 +560,14 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   }
   __syncthreads();
 
+  if (ALOAM_RF_STOP == 2) return;
   // ---- corner / flat selection (:284-390): every sector by its own wave, speculatively without the marks the previous
   // sectors leave on its first five points; those marks only matter if the sector picked one of the marked points, which
   // the second pass detects (and then redoes that sector with the marks) in sector order
   constexpr int K6 = (NPAD / 6 + 2 + 63) / 64;
   for (int j = wave; j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);
   __syncthreads();
+  if (ALOAM_RF_STOP == 3) return;
   if (wave == 0) {
     unsigned carry = (unsigned)s_misc[8];                                    // marks on the (up to 5) points after sector 0
     for (int j = 1; j < kSectors; ++j) {
@@ -499,6 +618,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // ---- labels out (parity / debugging) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
   for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
 
+  if (ALOAM_RF_STOP == 4) return;
   // ---- pcl::VoxelGrid (leaf 0.2) over the less-flat points of this ring (:401-405)
   float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
   for (int e = tid; e < L; e += 256) {
@@ -520,6 +640,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   int minb[3], divb[3];
   float fminb[3];
   bool overflow;
+  long long cells;
   {
     float gmn[3], gmx[3];
 #pragma unroll
@@ -535,12 +656,12 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       divb[q] = (int)floorf(gmx[q] * inv) - minb[q] + 1;
       fminb[q] = (float)minb[q];
     }
+    cells = (long long)divb[0] * divb[1] * divb[2];                          // every voxel index is below this
   }
   // Points follow the ring, so consecutive less-flat points mostly share a voxel: the sort works on RUNS of consecutive
   // same-voxel members, keyed (voxel index, first element), typically a third of the points.  Runs of one voxel end up adjacent
   // and in ascending element order, i.e. the members of a voxel are still summed in input order.
-  unsigned* vis = reinterpret_cast<unsigned*>(smem);                          // region A: voxel index per element [NPAD] ...
-  unsigned long long* rkeys = reinterpret_cast<unsigned long long*>(smem);    // ... replaced by the run keys [NPAD] once the heads are known
+  unsigned* vis = reinterpret_cast<unsigned*>(smem);                          // region A: voxel index per element [NPAD], later the run keys
   static_assert(8 * NPAD <= A_BYTES, "region A holds the voxel indices, then the run keys");
   for (int e = tid; e < L; e += 256) {
     const int i = e + 5;
@@ -558,100 +679,15 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     vis[e] = vi;
   }
   __syncthreads();
-  // run heads: a member whose predecessor is no member or sits in another voxel (members have label <= 0, never 0xffffffff).
-  // Elements are taken 256 at a time (element = it * 256 + tid: conflict-free LDS reads); the exclusive rank of a head in
-  // element order comes from wave ballots + a 4 x EIT table of wave counts — two barriers instead of a 16-barrier scan.
-  constexpr int EIT = NPAD / 256;
-  unsigned hmask = 0;                                                        // bit it: element it * 256 + tid starts a run
-  int hrank[EIT];
-  unsigned myvi[EIT];
-#pragma unroll
-  for (int it = 0; it < EIT; ++it) {
-    const int e = it * 256 + tid;
-    bool h = false;
-    myvi[it] = 0xffffffffu;
-    if (e < L) {
-      const unsigned vi = vis[e];
-      const bool member = label[e + 5] <= 0;
-      h = member && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi);
-      myvi[it] = vi;
-      flags[e + 5] = (unsigned char)(member && !h);                          // the element continues the run of its predecessor
-    }
-    const unsigned long long m = __ballot(h);
-    hrank[it] = __popcll(m & ((1ull << lane) - 1ull));
-    if (h) hmask |= 1u << it;
-    if (lane == 0) s_scan[it * 4 + wave] = __popcll(m);
-  }
-  __syncthreads();
-  int n_runs = 0;
-  {
-    int run = 0;
-#pragma unroll
-    for (int it = 0; it < EIT; ++it) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int c = s_scan[it * 4 + w];
-        if (w == wave) hrank[it] += run;
-        run += c;
-      }
-    }
-    n_runs = run;
-  }
-#pragma unroll
-  for (int it = 0; it < EIT; ++it)
-    if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = ((unsigned long long)myvi[it] << 32) | (unsigned long long)e; }   // vis is dead: every thread read its share before the barrier
-  __syncthreads();
-  bitonic_sort_u64(rkeys, n_runs, tid);
-
-  // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
-  unsigned vmask = 0;
-  int vrank[EIT];
-  __syncthreads();                                                           // s_scan is reused
-#pragma unroll
-  for (int it = 0; it < EIT; ++it) {
-    const int p = it * 256 + tid;
-    const bool h = p < n_runs && (p == 0 || (unsigned)(rkeys[p - 1] >> 32) != (unsigned)(rkeys[p] >> 32));
-    const unsigned long long m = __ballot(h);
-    vrank[it] = __popcll(m & ((1ull << lane) - 1ull));
-    if (h) vmask |= 1u << it;
-    if (lane == 0) s_scan[it * 4 + wave] = __popcll(m);
-  }
-  __syncthreads();
-  {
-    int run = 0;
-#pragma unroll
-    for (int it = 0; it < EIT; ++it) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int c = s_scan[it * 4 + w];
-        if (w == wave) vrank[it] += run;
-        run += c;
-      }
-    }
-    if (tid == 0) s_misc[0] = run;                                           // number of occupied voxels = less-flat points of this ring
-  }
+  if (ALOAM_RF_STOP == 5) return;
+  // 32-bit run keys (voxel index << EB | first element) whenever the voxel box is small enough — most rings: half the LDS
+  // traffic and a third fewer VALU instructions in the sort; the 64-bit keys remain for rings whose box has more cells.
+  constexpr int EB = NPAD <= 2048 ? 11 : 12;                                  // bits of an element index
   float4* out = a.lf_ring + (long long)b * a.cap + start;
-#pragma unroll
-  for (int it = 0; it < EIT; ++it) {
-    if (!((vmask >> it) & 1u)) continue;
-    const int p = it * 256 + tid;
-    const unsigned vi = (unsigned)(rkeys[p] >> 32);
-    float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
-    int cnt = 0;
-    for (int q = p; q < n_runs; ++q) {                                       // the runs of this voxel, in element order
-      const unsigned long long kq = rkeys[q];
-      if ((unsigned)(kq >> 32) != vi) break;
-      int e = (int)(unsigned)kq;
-      do {
-        const float4 pt = cloud[e + 5];
-        sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
-        ++cnt;
-        ++e;
-      } while (e < L && flags[e + 5]);                                        // the run stops at the next head or non-member
-    }
-    const float fc = (float)cnt;
-    out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
-  }
+  if (!ALOAM_RF_KEYS64 && (overflow || cells <= (1ll << (32 - EB))))
+    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave);
+  else
+    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave);
   __syncthreads();
   if (tid == 0) a.lf_cnt[b * a.R + r] = s_misc[0];
 }

@@ -88,19 +88,27 @@ def parse_args():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+SHARED_GPU_ENV = "ALOAM_BENCH_SHARED_GPU"   # test hook: let the ranks share the visible devices (control plane on gloo) on a 1-GPU box
+
+
+def rank_envs(n, port, base=None):
+    """Environment of each of the n ranks `python bench.py --gpus n` starts (what torch.distributed.run would export)."""
+    base = dict(os.environ if base is None else base)
+    return [dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")) for r in range(n)]
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU)."""
     import torch
     n = args.gpus
     have = torch.cuda.device_count()
-    assert have >= n, f"--gpus {n} but only {have} HIP device(s) are visible"
+    assert have >= n or os.environ.get(SHARED_GPU_ENV), f"--gpus {n} but only {have} HIP device(s) are visible"
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for env in rank_envs(n, port):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     for p in procs:
@@ -181,7 +189,7 @@ def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping):
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=wl.data.device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else wl.data.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if NC > 1:                                             # per-kernel profile from one extra, untimed pass on a single context
@@ -359,6 +367,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    shared = bool(os.environ.get(SHARED_GPU_ENV))
+    if shared:
+        local_rank %= torch.cuda.device_count()
     assert torch.cuda.device_count() > local_rank, f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} device(s) visible"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -366,7 +377,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # control plane only: barrier + MAX of the elapsed time
+        if shared:
+            dist.init_process_group("gloo")                # RCCL refuses two ranks on one device
+        else:
+            dist.init_process_group("nccl", device_id=dev) # control plane only: barrier + MAX of the elapsed time
 
     binding = importlib.import_module("a-loam_amd.binding")
     syn = importlib.import_module("a-loam_amd.synthetic")

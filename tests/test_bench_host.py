@@ -1,0 +1,50 @@
+"""Host-side logic of bench.py that needs no GPU: the ranks `--gpus N` starts itself, the replay order, the CPU-baseline worker."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_self_spawn_environment_is_what_a_launcher_would_export():
+    b = _bench()
+    envs = b.rank_envs(4, 29511, base={"PATH": "/x"})
+    assert [e["RANK"] for e in envs] == ["0", "1", "2", "3"] and [e["LOCAL_RANK"] for e in envs] == ["0", "1", "2", "3"]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29511" for e in envs)
+    assert all(e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/x" for e in envs)
+
+
+def test_gpus_flag_is_read():
+    """Round 1's bench parsed --gpus and never used it: `python bench.py --gpus 8` ran one rank."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "args.gpus > 1" in src and "self_spawn(args)" in src and '"n_gpus": world' in src
+
+
+def test_replay_order_keeps_consecutive_sweeps_adjacent():
+    b = _bench()
+    o = b.frame_order(6, 23)
+    assert o[:12] == [0, 1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1] and all(abs(x - y) == 1 for x, y in zip(o, o[1:]))
+    assert b.frame_order(1, 3) == [0, 0, 0]
+
+
+def test_cpu_baseline_worker(tmp_path, syn):
+    scans, R, t, model = syn.make_sequence("VLP-16", 3, seed=2, columns=300)
+    path = str(tmp_path / "s.npz")
+    np.savez(path, T=3, order=np.array([0, 1, 2, 1, 0]), n_scans=16, min_range=model.min_range, ring_from_field=0, line_res=0.2, plane_res=0.4,
+             **{f"s{k}": s.numpy() for k, s in enumerate(scans)})
+    for extra in ([], ["--mapping"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), path, "0.3"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        o = json.loads(r.stdout.strip().splitlines()[-1])
+        assert o["scans"] >= 3 and len(o["per_scan_ms"]) == o["scans"] and o["seconds"] > 0
