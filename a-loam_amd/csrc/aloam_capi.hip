@@ -18,11 +18,11 @@
 using namespace aloam;
 
 namespace {
-enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_COMPACT, K_BUILD_GRIDS, K_TRANSFORM, K_ASSOC_CORNER,
+enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_BUILD_GRIDS, K_TRANSFORM, K_ASSOC_CORNER,
                 K_ASSOC_PLANE, K_SOLVE, K_ADVANCE, K_MAP_BEGIN, K_MAP_VOXEL_STACK, K_MAP_GRID, K_MAP_ASSOC, K_MAP_SOLVE, K_MAP_INSERT,
                 K_MAP_VOXEL_CUBES, K_MAP_REGISTER, K_COUNT };
 const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_classify", "k_ring_offsets", "k_scatter", "k_ring_features",
-                                     "k_compact_features", "k_build_grids", "k_transform_queries", "k_associate[corner]", "k_associate[plane]",
+                                     "k_build_grids", "k_transform_queries", "k_associate[corner]", "k_associate[plane]",
                                      "k_solve", "k_advance", "map_begin", "map_voxel[stacks]", "map_grid", "map_associate", "map_solve",
                                      "map_insert", "map_voxel[cubes]", "map_register"};
 struct ProfRec { int kernel; hipEvent_t e0, e1; };
@@ -48,8 +48,8 @@ struct aloam_ctx {
   int8_t* d_ringid = nullptr; float* d_ori = nullptr;
   int *d_hist = nullptr, *d_blockoff = nullptr, *d_ringstart = nullptr;
   float4* d_cloud = nullptr; float* d_curv = nullptr; int8_t* d_label = nullptr;
-  int *d_sharp_idx = nullptr, *d_less_sharp_idx = nullptr, *d_flat_idx = nullptr, *d_pick_cnt = nullptr;
-  float4* d_lf_ring = nullptr; int* d_lf_cnt = nullptr;
+  unsigned long long* d_lookback = nullptr; unsigned reg_epoch = 0;   // ring-count granules of k_ring_features, launch counter
+  bool debug_arrays = false;                                         // the last registration wrote curvature / labels
   float4 *d_sharp = nullptr, *d_flat = nullptr;
   float4* d_less_sharp[2] = {nullptr, nullptr};
   float4* d_less_flat[2] = {nullptr, nullptr};
@@ -152,8 +152,7 @@ RegArgs reg_args(aloam_ctx* c, const void* d_scans, long long seq_stride, int pt
   a.ring_from_field = c->cfg.ring_from_field; a.min_range = c->cfg.min_range;
   a.meta = c->d_meta; a.ringid = c->d_ringid; a.ori = c->d_ori; a.hist = c->d_hist; a.blockoff = c->d_blockoff;
   a.ringstart = c->d_ringstart; a.cloud = c->d_cloud; a.curv = c->d_curv; a.label = c->d_label;
-  a.sharp_idx = c->d_sharp_idx; a.less_sharp_idx = c->d_less_sharp_idx; a.flat_idx = c->d_flat_idx; a.pick_cnt = c->d_pick_cnt;
-  a.lf_ring = c->d_lf_ring; a.lf_cnt = c->d_lf_cnt;
+  a.lookback = c->d_lookback; a.epoch = c->reg_epoch; a.store_debug = c->debug_arrays ? 1 : 0;
   a.sharp = c->d_sharp; a.less_sharp = c->d_less_sharp[c->cur]; a.flat = c->d_flat; a.less_flat = c->d_less_flat[c->cur];
   return a;
 }
@@ -195,7 +194,9 @@ int fetch_meta(aloam_ctx* c, int seq, SeqMeta* m) {
   return ALOAM_OK;
 }
 
-int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, const int* n_in, int stride_bytes, int slot = -1) {
+// debug_arrays: also write cloudCurvature / cloudLabel (the per-point entry points aloam_get_curvature / aloam_get_labels);
+// the throughput entries (aloam_process_device / aloam_process_host) leave those 5 bytes per point out.
+int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, const int* n_in, int stride_bytes, int slot = -1, bool debug_arrays = true) {
   if (stride_bytes < 16 || (stride_bytes & 3)) { c->err = "stride_bytes must be >= 16 and a multiple of 4"; return ALOAM_E_ARG; }
   for (int b = 0; b < c->B; ++b) {
     if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
@@ -209,6 +210,8 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   HIP_TRY(c, hipMemcpyAsync(c->d_nin, nin_slot, sizeof(int) * c->B, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->nin_done[ns], c->stream));
   c->nin_used[ns] = true;
+  c->debug_arrays = debug_arrays;
+  if (++c->reg_epoch == 0) c->reg_epoch = 1;
   const RegArgs a = reg_args(c, d_scans, seq_stride, stride_bytes);
   { ProfScope p(c, K_FIND_ENDS); launch_find_ends(a, c->d_nin, c->stream); }
   { ProfScope p(c, K_CLASSIFY); launch_classify(a, c->stream); }
@@ -216,7 +219,6 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   { ProfScope p(c, K_SCATTER); launch_scatter(a, c->stream); }
   if (slot >= 0) { HIP_TRY(c, hipEventRecord(c->in_consumed[slot], c->stream)); c->in_used[slot] = true; }   // the raw sweep is not read after this
   { ProfScope p(c, K_RING_FEATURES); launch_ring_features(a, c->npad, 0.2f, c->stream); }   // leaf 0.2 (src/scanRegistration.cpp:404)
-  { ProfScope p(c, K_COMPACT); launch_compact_features(a, c->stream); }
   HIP_TRY(c, hipGetLastError());
   c->have_features = true;
   return ALOAM_OK;
@@ -280,12 +282,7 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
   if ((rc = dmalloc(c, &c->d_cloud, B * cap))) return rc;
   if ((rc = dmalloc(c, &c->d_curv, B * cap))) return rc;
   if ((rc = dmalloc(c, &c->d_label, B * cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_sharp_idx, B * R * kSectors * kSharpPerSector))) return rc;
-  if ((rc = dmalloc(c, &c->d_less_sharp_idx, B * R * kSectors * kLessSharpPerSector))) return rc;
-  if ((rc = dmalloc(c, &c->d_flat_idx, B * R * kSectors * kFlatPerSector))) return rc;
-  if ((rc = dmalloc(c, &c->d_pick_cnt, B * R * kSectors * 3))) return rc;
-  if ((rc = dmalloc(c, &c->d_lf_ring, B * cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_lf_cnt, B * R))) return rc;
+  if ((rc = dmalloc(c, &c->d_lookback, B * 4 * R))) return rc;
   if ((rc = dmalloc(c, &c->d_sharp, B * R * 12))) return rc;
   if ((rc = dmalloc(c, &c->d_flat, B * R * 24))) return rc;
   for (int k = 0; k < 2; ++k) {
@@ -324,7 +321,7 @@ void aloam_destroy(aloam_ctx* c) {
   for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   void* bufs[] = {c->d_in[0], c->d_in[1], c->d_nin, c->d_meta, c->d_ringid, c->d_ori, c->d_hist, c->d_blockoff, c->d_ringstart, c->d_cloud, c->d_curv,
-                  c->d_label, c->d_sharp_idx, c->d_less_sharp_idx, c->d_flat_idx, c->d_pick_cnt, c->d_lf_ring, c->d_lf_cnt, c->d_sharp,
+                  c->d_label, c->d_lookback, c->d_sharp,
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes, c->d_sel_sharp, c->d_sel_flat,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
                   c->d_grid_start2[0], c->d_grid_start2[1],
@@ -410,7 +407,7 @@ int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in,
 // stream into the next of two device slabs, the kernels wait for it on the compute stream — so the copy of call k + 1 runs
 // under the kernels of call k.  Truly asynchronous only from pinned memory (hipHostMalloc / hipHostRegister); the runtime stages
 // pageable memory synchronously.  The buffer must stay unmodified until aloam_input_consumed() / aloam_synchronize().
-static int stage_and_register(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
+static int stage_and_register(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes, bool debug_arrays) {
   if (!c || !h_scans || !n_in) return ALOAM_E_ARG;
   if (stride_bytes < 16 || (stride_bytes & 3) || seq_stride_bytes < 0) { c->err = "bad stride"; return ALOAM_E_ARG; }
   int nmax = 0;
@@ -434,17 +431,17 @@ static int stage_and_register(aloam_ctx* c, const void* h_scans, long long seq_s
   }
   HIP_TRY(c, hipEventRecord(c->in_copied[slot], c->copy_stream));
   HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_copied[slot], 0));
-  return register_launch(c, c->d_in[slot], (long long)d_seq_stride, n_in, stride_bytes, slot);
+  return register_launch(c, c->d_in[slot], (long long)d_seq_stride, n_in, stride_bytes, slot, debug_arrays);
 }
 
 int aloam_scan_register_host(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
   DeviceScope device_scope(c);
-  return stage_and_register(c, h_scans, seq_stride_bytes, n_in, stride_bytes);
+  return stage_and_register(c, h_scans, seq_stride_bytes, n_in, stride_bytes, true);
 }
 
 int aloam_process_host(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
   DeviceScope device_scope(c);
-  const int rc = stage_and_register(c, h_scans, seq_stride_bytes, n_in, stride_bytes);
+  const int rc = stage_and_register(c, h_scans, seq_stride_bytes, n_in, stride_bytes, false);
   if (rc) return rc;
   return aloam_odometry_step(c);
 }
@@ -483,7 +480,8 @@ int aloam_odometry_step(aloam_ctx* c) {
 
 int aloam_process_device(aloam_ctx* c, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes) {
   DeviceScope device_scope(c);
-  const int rc = aloam_scan_register_device(c, d_scans, seq_stride_bytes, n_in, stride_bytes);
+  if (!c || !d_scans || !n_in) return ALOAM_E_ARG;
+  const int rc = register_launch(c, d_scans, seq_stride_bytes, n_in, stride_bytes, -1, /*debug_arrays=*/false);
   if (rc) return rc;
   return aloam_odometry_step(c);
 }
@@ -630,6 +628,7 @@ int aloam_get_curvature(aloam_ctx* c, int seq, float* out, int cap) {
   DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
+  if (!c->debug_arrays) { c->err = "curvature is only kept by aloam_scan_register*; the throughput entries (aloam_process_*) skip it"; return ALOAM_E_STATE; }
   SeqMeta m;
   if ((rc = fetch_meta(c, seq, &m))) return rc;
   const int k = m.n_cloud < cap ? m.n_cloud : cap;
@@ -641,6 +640,7 @@ int aloam_get_labels(aloam_ctx* c, int seq, int* out, int cap) {
   DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
+  if (!c->debug_arrays) { c->err = "labels are only kept by aloam_scan_register*; the throughput entries (aloam_process_*) skip them"; return ALOAM_E_STATE; }
   SeqMeta m;
   if ((rc = fetch_meta(c, seq, &m))) return rc;
   const int k = m.n_cloud < cap ? m.n_cloud : cap;
@@ -720,8 +720,7 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
         case K_CLASSIFY: bytes += 16 * Nin + 5 * Nin; break;
         case K_RING_OFFSETS: bytes += 8.0 * c->NB * c->R; break;
         case K_SCATTER: bytes += 21 * Nin + 16 * N; break;
-        case K_RING_FEATURES: bytes += 16 * N + 5 * N + 16 * Ls; break;
-        case K_COMPACT: bytes += 32 * (Fc + Lc + Fs) + 32 * Ls; break;
+        case K_RING_FEATURES: bytes += 16 * N + (c->debug_arrays ? 5 * N : 0) + 16 * (Fc + Lc + Fs + Ls); break;   // ring-ordered cloud in, the four feature clouds out (+ curvature / labels for the parity entry points)
         case K_BUILD_GRIDS: bytes += 16 * (Lcl + Lsl) + 48 * (Lcl + Lsl) + 12.0 * (c->grid_H[0] + c->grid_H[1]); break;   // read once, three sorted copies + three bucket tables out
         case K_TRANSFORM: bytes += 32 * (Fc + Fs); break;
         case K_ASSOC_CORNER: bytes += 16 * (Fc + Lcl) + 48 * Fc; break;

@@ -63,12 +63,9 @@ struct RegArgs {
   float4* cloud;             // [B][cap] ring-ordered
   float* curv;               // [B][cap]
   int8_t* label;             // [B][cap]
-  int* sharp_idx;            // [B][R][6][2]   indices into cloud
-  int* less_sharp_idx;       // [B][R][6][20]
-  int* flat_idx;             // [B][R][6][4]
-  int* pick_cnt;             // [B][R][6][3]   (sharp, less_sharp, flat)
-  float4* lf_ring;           // [B][cap] per-ring voxel output, stored at the ring's offset
-  int* lf_cnt;               // [B][R]
+  unsigned long long* lookback;   // [B][4][R] {launch epoch, count} granules: points per ring and output class (k_ring_features)
+  unsigned epoch;            // this launch; never 0 (the buffer starts zeroed)
+  int store_debug;           // 1: also write curv / label (parity tests); the throughput entries leave them out
   float4* sharp;             // [B][R*12]
   float4* less_sharp;        // [B][R*120]   (current buffer)
   float4* flat;              // [B][R*24]

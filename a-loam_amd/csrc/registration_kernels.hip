@@ -11,15 +11,12 @@
 //                                tiles; std::sort + greedy corner / flat picking with neighbour suppression evaluated as
 //                                an iterative arg-max per sector (no sort); less-flat gather + 0.2 m voxel centroids
 //                                (pcl::VoxelGrid stand-in: runs of same-voxel points sorted by an LDS bitonic)
-//   k_compact_features :304-310,356,407  append per-(ring,sector) picks in the reference's output order
+//                              ; the ring workgroups publish their counts to each other, so every pick and every less-flat
+//                                centroid is written once, at its final place in the reference's output order (:304-310,356,407)
 //
 // All of it is HBM/latency-bound integer + f32 work: coalesced 16-B loads, LDS staging, wave64 ballots; no MFMA.
 #include "aloam_device.hpp"
 #include "registration_kernels.hpp"
-
-#ifndef ALOAM_RF_STOP
-#define ALOAM_RF_STOP 0     // phase-timing builds only: k_ring_features returns after phase N (0 = the product)
-#endif
 
 namespace aloam {
 
@@ -263,6 +260,30 @@ __device__ __forceinline__ unsigned wave_extreme_u32(unsigned v, int lane) {
   return best;
 }
 
+// ---- output offsets across the rings of a sweep --------------------------------------------------------------------------------
+// The four feature clouds are the ring-by-ring concatenation of what the ring workgroups produce (reference
+// src/scanRegistration.cpp:304-310,356,407), so a workgroup needs the counts of the rings in front of it.  Every (sweep, ring)
+// workgroup publishes its own count per class as ONE 8-byte granule {launch epoch, count}: the value is its own flag, nothing has
+// to be reset between launches, and a reader needs no other data of the writer (MI355X_MICROARCH.md, inter-workgroup visibility:
+// agent-scope loads of 8-byte granules).  A reader gathers the granules of the rings in front of it with one wave (lane = ring)
+// and sums them: no serial ripple from ring to ring.  Waiting cannot deadlock: a workgroup only waits for workgroups with a lower
+// linear id, and those are dispatched first.
+__device__ __forceinline__ void publish_count(unsigned long long* slot, unsigned epoch, int count) {
+  __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int gather_counts(const unsigned long long* slots, int upto, unsigned epoch, int lane) {   // whole wave
+  int sum = 0;
+  for (int base = 0; base < upto; base += 64) {
+    const int q = base + lane;
+    if (q < upto) {
+      unsigned long long g;
+      while ((unsigned)((g = __hip_atomic_load(slots + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+      sum += (int)(unsigned)g;
+    }
+  }
+  sum = wave_scan_i32<false>(sum);
+  return __builtin_amdgcn_readlane(sum, 63);
+}
 // Greedy corner / flat selection of ONE sector by ONE wave, with the whole sector in registers (reference
 // src/scanRegistration.cpp:284-390).  std::sort + "walk from the top, skip picked points" is evaluated as an iterative arg-max
 // over the still-unpicked points (arg-min for the flat points): same picks in the same order — ties in curvature go to the
@@ -355,8 +376,9 @@ __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, i
 // ---- second half of pcl::VoxelGrid for one ring: run heads -> sort of the run keys -> voxel heads ->
 // centroids in input order.  K = key type (voxel index << SHIFT | first element of the run), see the call site.
 template <int NPAD, typename K, int SHIFT>
-__device__ __forceinline__ void voxel_runs_tail(unsigned char* smem, unsigned char* flags, const signed char* label, int* s_scan, int* s_misc,
-                                                const float4* cloud, float4* out, int L, int tid, int lane, int wave) {
+__device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned char* flags, const signed char* label, int* s_scan, int* s_misc,
+                                               const float4* cloud, float4* out, int L, int tid, int lane, int wave,
+                                               unsigned long long* lb_lf, int ring, int nrings, unsigned epoch) {
   const unsigned* vis = reinterpret_cast<const unsigned*>(smem);               // region A: voxel index per element [NPAD] ...
   K* rkeys = reinterpret_cast<K*>(smem);                                      // ... replaced by the run keys once the heads are known
   constexpr unsigned kEMask = SHIFT >= 32 ? 0xffffffffu : ((1u << (SHIFT & 31)) - 1u);
@@ -403,11 +425,10 @@ __device__ __forceinline__ void voxel_runs_tail(unsigned char* smem, unsigned ch
   for (int it = 0; it < EIT; ++it)
     if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = (K)(((K)myvi[it] << SHIFT) | (K)e); }   // vis is dead: every thread read its share before the barrier
   __syncthreads();
-  if (ALOAM_RF_STOP == 6) return;
   bitonic_sort_keys<K>(rkeys, n_runs, tid);
-  if (ALOAM_RF_STOP == 7) return;
 
   // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
+  int n_vox = 0;
   unsigned vmask = 0;
   int vrank[EIT];
   __syncthreads();                                                           // s_scan is reused
@@ -432,8 +453,20 @@ __device__ __forceinline__ void voxel_runs_tail(unsigned char* smem, unsigned ch
         run += c;
       }
     }
-    if (tid == 0) s_misc[0] = run;                                           // number of occupied voxels = less-flat points of this ring
+    if (tid == 0) publish_count(lb_lf + ring, epoch, run);                   // number of occupied voxels = less-flat points of this ring
+    n_vox = run;
   }
+  // offsets of this ring in the four clouds = what the rings in front produced.  The launch orders the workgroups ring-major
+  // over the sweeps of the batch (blockIdx.x = sweep), so the rings in front of this one were dispatched a whole batch row
+  // earlier and have normally published long ago: the gather does not wait.
+  if (wave == 0) {
+    const unsigned long long* lb0 = lb_lf - 3 * nrings;
+    const int b0 = gather_counts(lb0 + 0 * nrings, ring, epoch, lane), b1 = gather_counts(lb0 + 1 * nrings, ring, epoch, lane);
+    const int b2 = gather_counts(lb0 + 2 * nrings, ring, epoch, lane), b3 = gather_counts(lb_lf, ring, epoch, lane);
+    if (lane == 0) { s_misc[40] = b0; s_misc[41] = b1; s_misc[42] = b2; s_misc[43] = b3; }
+  }
+  __syncthreads();
+  out += s_misc[43];
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
     if (!((vmask >> it) & 1u)) continue;
@@ -455,20 +488,22 @@ __device__ __forceinline__ void voxel_runs_tail(unsigned char* smem, unsigned ch
     const float fc = (float)cnt;
     out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
   }
+  return n_vox;
 }
 
 template <int NPAD>
 __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int MAXN = NPAD + 11;
   constexpr int ITEMS = (MAXN + 255) / 256;
-  const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // ring-major over the batch, see voxel_runs_tail
   const int start = a.ringstart[b * (a.R + 1) + r];
   const int n = a.ringstart[b * (a.R + 1) + r + 1] - start;
-  int* pick_cnt = a.pick_cnt + ((long long)(b * a.R + r) * kSectors) * 3;
-  if (tid < kSectors * 3) pick_cnt[tid] = 0;
-  if (tid == 0) a.lf_cnt[b * a.R + r] = 0;
-  if (n - 11 < 6) return;                                                   // :279
-  if (n > MAXN) { if (tid == 0) atomicOr(&a.meta[b].err, kErrRingCap); return; }
+  unsigned long long* lb = a.lookback + (long long)b * 4 * a.R;             // [class][ring] count granules of this sweep
+  if (n - 11 < 6 || n > MAXN) {                                             // :279: nothing is selected from this ring
+    if (n - 11 >= 6 && tid == 0) atomicOr(&a.meta[b].err, kErrRingCap);
+    if (tid < 4) publish_count(lb + tid * a.R + r, a.epoch, 0);
+    return;
+  }
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // region A (aliased over time): two 266-point xyz tiles during the curvature pass, then the curvature per point, then the voxel
@@ -487,7 +522,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // picks of the 6 sectors (local indices), staged in LDS so that the serial picking loop issues no global store:
   // [j][0..1] sharp, [j][2..21] less sharp, [j][22..25] flat
   constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
-  short* s_pick = reinterpret_cast<short*>(s_misc + 16);
+  short* s_pick = reinterpret_cast<short*>(s_misc + 48);      // s_misc: [0] scratch, [1..6] pick counts, [8..13] spill marks, [16..], [24..], [32..] sector offsets
 
   const float4* cloud = a.cloud + (long long)b * a.cap + start;
   // ---- curvature (:256-266) + gap flags, kept in registers until the tiles are retired.  The ring goes through LDS in chunks
@@ -523,7 +558,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
         const float dY = ys[-5] + ys[-4] + ys[-3] + ys[-2] + ys[-1] - 10 * ys[0] + ys[1] + ys[2] + ys[3] + ys[4] + ys[5];
         const float dZ = zs[-5] + zs[-4] + zs[-3] + zs[-2] + zs[-1] - 10 * zs[0] + zs[1] + zs[2] + zs[3] + zs[4] + zs[5];
         cv[it] = dX * dX + dY * dY + dZ * dZ;
-        a.curv[(long long)b * a.cap + start + i] = cv[it];
+        if (a.store_debug) a.curv[(long long)b * a.cap + start + i] = cv[it];
       }
       flags[i] = f;
       label[i] = 0;
@@ -536,7 +571,6 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     __syncthreads();
   }
 
-  if (ALOAM_RF_STOP == 1) return;
   // reach of the neighbour suppression around every point: a pick of i marks i+1 .. i+fw and i-1 .. i-bk (runs of consecutive
   // gap-free steps, at most 5).  Packed into the flag byte: bit1 gap, bits 2-4 fw, bits 5-7 bk.
   unsigned char rb[ITEMS];
@@ -560,14 +594,12 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   }
   __syncthreads();
 
-  if (ALOAM_RF_STOP == 2) return;
   // ---- corner / flat selection (:284-390): every sector by its own wave, speculatively without the marks the previous
   // sectors leave on its first five points; those marks only matter if the sector picked one of the marked points, which
   // the second pass detects (and then redoes that sector with the marks) in sector order
   constexpr int K6 = (NPAD / 6 + 2 + 63) / 64;
   for (int j = wave; j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);
   __syncthreads();
-  if (ALOAM_RF_STOP == 3) return;
   if (wave == 0) {
     unsigned carry = (unsigned)s_misc[8];                                    // marks on the (up to 5) points after sector 0
     for (int j = 1; j < kSectors; ++j) {
@@ -597,28 +629,26 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       else { const int q = slot - kSharpPerSector - kLessSharpPerSector; if (q < nfl) label[s_pick[j * kSlots + slot]] = -1; }
     }
   }
-  int* sharp_idx = a.sharp_idx + ((long long)(b * a.R + r) * kSectors) * kSharpPerSector;
-  int* less_idx = a.less_sharp_idx + ((long long)(b * a.R + r) * kSectors) * kLessSharpPerSector;
-  int* flat_idx = a.flat_idx + ((long long)(b * a.R + r) * kSectors) * kFlatPerSector;
   __syncthreads();
-  // picks out: sharp = the first two less-sharp picks (:301-311)
-  if (tid < kSectors * kSlots) {
-    const int j = tid / kSlots, slot = tid % kSlots;
-    const int ncorner = s_misc[1 + j] & 0xff, nflat = s_misc[1 + j] >> 8;
-    if (slot < kSharpPerSector) { if (slot < ncorner) sharp_idx[j * kSharpPerSector + slot] = start + s_pick[j * kSlots + kSharpPerSector + slot]; }
-    else if (slot < kSharpPerSector + kLessSharpPerSector) { const int q = slot - kSharpPerSector; if (q < ncorner) less_idx[j * kLessSharpPerSector + q] = start + s_pick[j * kSlots + slot]; }
-    else { const int q = slot - kSharpPerSector - kLessSharpPerSector; if (q < nflat) flat_idx[j * kFlatPerSector + q] = start + s_pick[j * kSlots + slot]; }
-    if (slot == 0) {
-      pick_cnt[j * 3 + 0] = ncorner < kSharpPerSector ? ncorner : kSharpPerSector;
-      pick_cnt[j * 3 + 1] = ncorner;
-      pick_cnt[j * 3 + 2] = nflat;
+  // ---- counts of this ring per class -> published right away (no waiting); the picks themselves are written at the very end,
+  // together with the less-flat centroids, once the counts of the rings in front are in (they are dispatched earlier and are
+  // about to finish by then)
+  if (wave == 0) {
+    int nc = 0, nf = 0;
+    if (lane < kSectors) { nc = s_misc[1 + lane] & 0xff; nf = s_misc[1 + lane] >> 8; }
+    const int ns = nc < kSharpPerSector ? nc : kSharpPerSector;
+    const int is = wave_scan_i32<false>(ns), il = wave_scan_i32<false>(nc), ifl = wave_scan_i32<false>(nf);
+    if (lane < kSectors) { s_misc[16 + lane] = is - ns; s_misc[24 + lane] = il - nc; s_misc[32 + lane] = ifl - nf; }   // exclusive over the sectors
+    if (lane == 0) {
+      publish_count(lb + 0 * a.R + r, a.epoch, __builtin_amdgcn_readlane(is, 63));
+      publish_count(lb + 1 * a.R + r, a.epoch, __builtin_amdgcn_readlane(il, 63));
+      publish_count(lb + 2 * a.R + r, a.epoch, __builtin_amdgcn_readlane(ifl, 63));
     }
   }
 
-  // ---- labels out (parity / debugging) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
-  for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
+  // ---- labels out (parity tests only) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
+  if (a.store_debug) for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
 
-  if (ALOAM_RF_STOP == 4) return;
   // ---- pcl::VoxelGrid (leaf 0.2) over the less-flat points of this ring (:401-405)
   float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
   for (int e = tid; e < L; e += 256) {
@@ -679,63 +709,41 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     vis[e] = vi;
   }
   __syncthreads();
-  if (ALOAM_RF_STOP == 5) return;
   // 32-bit run keys (voxel index << EB | first element) whenever the voxel box is small enough — most rings: half the LDS
   // traffic and a third fewer VALU instructions in the sort; the 64-bit keys remain for rings whose box has more cells.
   constexpr int EB = NPAD <= 2048 ? 11 : 12;                                  // bits of an element index
-  float4* out = a.lf_ring + (long long)b * a.cap + start;
+  float4* out = a.less_flat + (long long)b * a.cap;                          // final place: offset = less-flat points of the rings in front
   if (!ALOAM_RF_KEYS64 && (overflow || cells <= (1ll << (32 - EB))))
-    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave);
+    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch);
   else
-    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave);
-  __syncthreads();
-  if (tid == 0) a.lf_cnt[b * a.R + r] = s_misc[0];
-}
-
-// -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact_features(RegArgs a) {
-  const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  __shared__ int s_base[4];          // sharp, less_sharp, flat, less_flat offsets of this ring
-  __shared__ int s_own[4];
-  const int* pc = a.pick_cnt + (long long)b * a.R * kSectors * 3;
-  const int* lc = a.lf_cnt + b * a.R;
-  if (tid < 4) { s_base[tid] = 0; s_own[tid] = 0; }
-  __syncthreads();
-  int acc[4] = {0, 0, 0, 0}, own[4] = {0, 0, 0, 0};
-  for (int q = tid; q < (r + 1) * kSectors; q += 256) {
-    const int rr = q / kSectors;
-    for (int c = 0; c < 3; ++c) { const int v = pc[q * 3 + c]; if (rr < r) acc[c] += v; else own[c] += v; }
-  }
-  for (int q = tid; q <= r; q += 256) { if (q < r) acc[3] += lc[q]; else own[3] += lc[q]; }
-  for (int c = 0; c < 4; ++c) { if (acc[c]) atomicAdd(&s_base[c], acc[c]); if (own[c]) atomicAdd(&s_own[c], own[c]); }
-  __syncthreads();
-  const float4* cloud = a.cloud + (long long)b * a.cap;
-  const int nslot[3] = {kSharpPerSector, kLessSharpPerSector, kFlatPerSector};
-  const int* idx[3] = {a.sharp_idx + (long long)(b * a.R + r) * kSectors * kSharpPerSector,
-                       a.less_sharp_idx + (long long)(b * a.R + r) * kSectors * kLessSharpPerSector,
-                       a.flat_idx + (long long)(b * a.R + r) * kSectors * kFlatPerSector};
-  float4* dst[3] = {a.sharp + (long long)b * a.R * 12, a.less_sharp + (long long)b * a.R * 120, a.flat + (long long)b * a.R * 24};
-  constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;   // 26 pick slots per sector
-  if (tid < kSectors * kSlots) {
-    const int j = tid / kSlots, slot = tid % kSlots;
-    const int c = slot < kSharpPerSector ? 0 : (slot < kSharpPerSector + kLessSharpPerSector ? 1 : 2);
-    const int sidx = slot - (c == 0 ? 0 : (c == 1 ? kSharpPerSector : kSharpPerSector + kLessSharpPerSector));
-    if (sidx < pc[(r * kSectors + j) * 3 + c]) {
-      int o = s_base[c] + sidx;
-      for (int jj = 0; jj < j; ++jj) o += pc[(r * kSectors + jj) * 3 + c];
-      dst[c][o] = cloud[idx[c][j * nslot[c] + sidx]];
+    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch);
+  // the picked points go straight to their final place in the three clouds, in the reference's order (ring, sector, pick order;
+  // sharp = the first two less-sharp picks, :301-311)
+  if (wave == 0) {
+    const int base_sharp = s_misc[40], base_less = s_misc[41], base_flat = s_misc[42];
+    for (int q = lane; q < kSectors * kSlots; q += 64) {
+      const int j = q / kSlots, slot = q % kSlots;
+      const int ncorner = s_misc[1 + j] & 0xff, nflat = s_misc[1 + j] >> 8;
+      if (slot < kSharpPerSector) {
+        if (slot < ncorner) a.sharp[(long long)b * a.R * 12 + base_sharp + s_misc[16 + j] + slot] = cloud[s_pick[j * kSlots + kSharpPerSector + slot]];
+      } else if (slot < kSharpPerSector + kLessSharpPerSector) {
+        const int k = slot - kSharpPerSector;
+        if (k < ncorner) a.less_sharp[(long long)b * a.R * 120 + base_less + s_misc[24 + j] + k] = cloud[s_pick[j * kSlots + slot]];
+      } else {
+        const int k = slot - kSharpPerSector - kLessSharpPerSector;
+        if (k < nflat) a.flat[(long long)b * a.R * 24 + base_flat + s_misc[32 + j] + k] = cloud[s_pick[j * kSlots + slot]];
+      }
     }
   }
-  const int start = a.ringstart[b * (a.R + 1) + r];
-  const float4* src = a.lf_ring + (long long)b * a.cap + start;
-  float4* lf = a.less_flat + (long long)b * a.cap + s_base[3];
-  for (int q = tid; q < s_own[3]; q += 256) lf[q] = src[q];
-  if (r == a.R - 1 && tid == 0) {
-    a.meta[b].n_sharp = s_base[0] + s_own[0];
-    a.meta[b].n_less_sharp = s_base[1] + s_own[1];
-    a.meta[b].n_flat = s_base[2] + s_own[2];
-    a.meta[b].n_less_flat = s_base[3] + s_own[3];
-  }
+}
+
+// Sizes of the four feature clouds of every sweep = sums of the published ring counts (one wave per sweep).
+__global__ __launch_bounds__(64) void k_cloud_sizes(RegArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const unsigned long long* lb = a.lookback + (long long)b * 4 * a.R;
+  const int n0 = gather_counts(lb + 0 * a.R, a.R, a.epoch, lane), n1 = gather_counts(lb + 1 * a.R, a.R, a.epoch, lane);
+  const int n2 = gather_counts(lb + 2 * a.R, a.R, a.epoch, lane), n3 = gather_counts(lb + 3 * a.R, a.R, a.epoch, lane);
+  if (lane == 0) { a.meta[b].n_sharp = n0; a.meta[b].n_less_sharp = n1; a.meta[b].n_flat = n2; a.meta[b].n_less_flat = n3; }
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -743,7 +751,7 @@ size_t ring_features_lds_bytes(int npad) {
   const int maxn = npad + 11;
   const int a_bytes = 8 * npad;
   const int flag_bytes = (maxn + 15) & ~15;
-  return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 16) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
+  return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 48) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
 }
 
 void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s) { hipLaunchKernelGGL(k_find_ends, dim3(a.B), dim3(1024), 0, s, a, d_nin); }
@@ -752,9 +760,9 @@ void launch_ring_offsets(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k
 void launch_scatter(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_scatter, dim3(a.NB, a.B), dim3(256), 0, s, a); }
 void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s) {
   const size_t lds = ring_features_lds_bytes(npad);
-  if (npad <= 2048) hipLaunchKernelGGL(k_ring_features<2048>, dim3(a.R, a.B), dim3(256), lds, s, a, leaf);
-  else hipLaunchKernelGGL(k_ring_features<4096>, dim3(a.R, a.B), dim3(256), lds, s, a, leaf);
+  if (npad <= 2048) hipLaunchKernelGGL(k_ring_features<2048>, dim3(a.B, a.R), dim3(256), lds, s, a, leaf);
+  else hipLaunchKernelGGL(k_ring_features<4096>, dim3(a.B, a.R), dim3(256), lds, s, a, leaf);
+  hipLaunchKernelGGL(k_cloud_sizes, dim3(a.B), dim3(64), 0, s, a);
 }
-void launch_compact_features(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_compact_features, dim3(a.R, a.B), dim3(256), 0, s, a); }
 
 }  // namespace aloam

@@ -9,5 +9,4 @@ void launch_classify(const RegArgs& a, hipStream_t s);
 void launch_ring_offsets(const RegArgs& a, hipStream_t s);
 void launch_scatter(const RegArgs& a, hipStream_t s);
 void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s);
-void launch_compact_features(const RegArgs& a, hipStream_t s);
 }  // namespace aloam

@@ -139,6 +139,8 @@ int aloam_set_state(aloam_ctx* ctx, int seq, const double para_q[4], const doubl
 int aloam_set_system_inited(aloam_ctx* ctx, int inited);             /* systemInited (src/laserOdometry.cpp:69,267-271) */
 
 /* ---- intermediate arrays, for parity tests ----------------------------------------------------------------- */
+/* cloudCurvature / cloudLabel are kept by the aloam_scan_register* entries only; after aloam_process_device / aloam_process_host
+ * (which skip those 5 bytes per point) the two getters fail with ALOAM_E_STATE. */
 int aloam_get_ring_ranges(aloam_ctx* ctx, int seq, int* start, int* count);     /* scanStartInd-5 / ring sizes (src/scanRegistration.cpp:246-252) */
 int aloam_get_curvature(aloam_ctx* ctx, int seq, float* out, int cap);          /* cloudCurvature (src/scanRegistration.cpp:66,262)               */
 int aloam_get_labels(aloam_ctx* ctx, int seq, int* out, int cap);               /* cloudLabel (src/scanRegistration.cpp:69)                       */
