@@ -132,8 +132,21 @@ __device__ __forceinline__ unsigned hash3(int a, int b, int c) {
   return ((unsigned)a * 73856093u) ^ ((unsigned)b * 19349663u) ^ ((unsigned)c * 83492791u);
 }
 
-__global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
-  const int b = blockIdx.y, which = blockIdx.x, tid = threadIdx.x;      // which: 0 corner_last, 1 surf_last
+#ifndef ALOAM_BG_WAVES
+#define ALOAM_BG_WAVES 4      // waves per SIMD the register budget is sized for (A/B builds)
+#endif
+#ifndef ALOAM_BG_SPLIT
+#define ALOAM_BG_SPLIT 1      // measured at batch 512: 2 workgroups x 3 passes 1.16 ms, 6 workgroups x 1 pass 0.85 ms
+#endif
+#ifndef ALOAM_BG_UNROLL
+#define ALOAM_BG_UNROLL 4
+#endif
+__global__ __launch_bounds__(1024, ALOAM_BG_WAVES) void k_build_grids(OdomArgs a) {
+  constexpr int U = ALOAM_BG_UNROLL;                                     // loads in flight per thread
+  // one workgroup per (sequence, cloud, grid): the three grids of a cloud are independent, and six workgroups per sequence
+  // overlap each other's load / LDS-atomic / scattered-store phases better than two that run three passes back to back
+  const int b = blockIdx.y, which = ALOAM_BG_SPLIT ? blockIdx.x / 3 : blockIdx.x, tid = threadIdx.x;      // which: 0 corner_last, 1 surf_last
+  const int pass_lo = ALOAM_BG_SPLIT ? blockIdx.x % 3 : 0, pass_hi = ALOAM_BG_SPLIT ? pass_lo + 1 : 3;
   const SeqMeta m = a.meta[b];
   const int n = which == 0 ? m.n_corner_last : m.n_surf_last;
   const float4* pts = which == 0 ? a.corner_last + (long long)b * a.R * 120 : a.surf_last + (long long)b * a.cap;
@@ -144,17 +157,17 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
   int* s_flag = part + 1024;              // bad, unsorted
   if (tid < 2) s_flag[tid] = n >= (1 << 20) && tid == 0 ? 1 : 0;
   if (n == 0) {
-    for (int pass = 0; pass < 3; ++pass) { int* st = pass == 0 ? g.start3 : pass == 1 ? g.start3c : g.start2; for (int h = tid; h <= g.H; h += 1024) st[h] = 0; }
-    if (tid < 2) g.flags[tid] = 0;
+    for (int pass = pass_lo; pass < pass_hi; ++pass) { int* st = pass == 0 ? g.start3 : pass == 1 ? g.start3c : g.start2; for (int h = tid; h <= g.H; h += 1024) st[h] = 0; }
+    if (tid < 2 && pass_lo == 0) g.flags[tid] = 0;
     return;
   }
   // The loops below keep the loads of the next round in flight while the current one is binned: on this ISA a wait for
   // loaded data also waits for every older store, so loads are always issued ahead of the stores they must not wait for.
   auto fetch = [&](int base, float4* p) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { const int i = base + u * 1024 + tid; p[u] = pts[i < n ? i : n - 1]; }
+    for (int u = 0; u < U; ++u) { const int i = base + u * 1024 + tid; p[u] = pts[i < n ? i : n - 1]; }
   };
-  for (int pass = 0; pass < 3; ++pass) {          // 0: G3, 1: G3 coarse, 2: G2
+  for (int pass = pass_lo; pass < pass_hi; ++pass) {          // 0: G3, 1: G3 coarse, 2: G2
     const bool g3 = pass < 2;
     const float cell = pass == 0 ? cell3_of(which) : pass == 1 ? cell3_of(which) * kCell3CoarseFactor : kCell2;
     const float inv = 1.0f / cell;
@@ -163,24 +176,24 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
     __syncthreads();
     for (int h = tid; h < g.H; h += 1024) cnt[h] = 0;
     __syncthreads();
-    float4 p[4], pn[4];
-    float pw[4], pwn[4];                          // pass 0: intensity of the point before, for the ring-sorted test
+    float4 p[U], pn[U];
+    float pw[U], pwn[U];                          // pass 0: intensity of the point before, for the ring-sorted test
     fetch(0, p);
     if (pass == 0) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { const int i = u * 1024 + tid; pw[u] = pts[i < n ? (i > 0 ? i - 1 : 0) : n - 1].w; }
+      for (int u = 0; u < U; ++u) { const int i = u * 1024 + tid; pw[u] = pts[i < n ? (i > 0 ? i - 1 : 0) : n - 1].w; }
     }
     int bad = 0, unsorted = 0;
-    for (int base = 0; base < n; base += 4096) {
-      if (base + 4096 < n) {
-        fetch(base + 4096, pn);
+    for (int base = 0; base < n; base += U * 1024) {
+      if (base + U * 1024 < n) {
+        fetch(base + U * 1024, pn);
         if (pass == 0) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int i = base + 4096 + u * 1024 + tid; pwn[u] = pts[i < n ? i - 1 : n - 1].w; }
+          for (int u = 0; u < U; ++u) { const int i = base + U * 1024 + u * 1024 + tid; pwn[u] = pts[i < n ? i - 1 : n - 1].w; }
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         if (base + u * 1024 + tid >= n) continue;
         const int key = (int)p[u].w;
         if (pass == 0) {
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
         atomicAdd(&cnt[hash3(ix, iy, iz) & (g.H - 1)], 1);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { p[u] = pn[u]; pw[u] = pwn[u]; }
+      for (int u = 0; u < U; ++u) { p[u] = pn[u]; pw[u] = pwn[u]; }
     }
     if (pass == 0) {
       if (bad) atomicOr(&s_flag[0], 1);
@@ -218,10 +231,10 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
     if (tid == 1023) start[g.H] = run;
     __syncthreads();
     fetch(0, p);
-    for (int base = 0; base < n; base += 4096) {
-      if (base + 4096 < n) fetch(base + 4096, pn);
+    for (int base = 0; base < n; base += U * 1024) {
+      if (base + U * 1024 < n) fetch(base + U * 1024, pn);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int i = base + u * 1024 + tid;
         if (i >= n) continue;
         const int key = (int)p[u].w;
@@ -231,7 +244,7 @@ __global__ __launch_bounds__(1024) void k_build_grids(OdomArgs a) {
         sorted[pos] = make_float4(p[u].x, p[u].y, p[u].z, __uint_as_float((unsigned)i | ((unsigned)(key + 1) << 20)));
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p[u] = pn[u];
+      for (int u = 0; u < U; ++u) p[u] = pn[u];
     }
   }
 }
@@ -746,7 +759,7 @@ void launch_build_grids(const OdomArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)k_build_grids, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_grids_lds_bytes(a.grid_H_surf, kMaxRings));
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(k_build_grids, dim3(2, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
+  hipLaunchKernelGGL(k_build_grids, dim3(ALOAM_BG_SPLIT ? 6 : 2, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
 }
 void launch_transform_queries(const OdomArgs& a, hipStream_t s) {
   const dim3 grid((a.R * 36 + 255) / 256, a.B);
