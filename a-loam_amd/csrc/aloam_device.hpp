@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "aloam_atan.hpp"
 
 namespace aloam {
 
@@ -129,72 +130,6 @@ __device__ __forceinline__ bool point_kept(const float4& p, float thres) {
   if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return false;
   const float r2 = p.x * p.x + p.y * p.y + p.z * p.z;
   return !(r2 < thres * thres);
-}
-
-// ---- atan2f, FDLIBM-style float algorithm: identical bits to glibc 2.35's atan2f, which is what
-// `atan2` resolves to at reference src/scanRegistration.cpp:141-142,208 (using std::atan2, :56). ----
-__device__ __forceinline__ float atanf_port(float x) {
-  const float hi[4] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
-  const float lo[4] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
-  const int hx = __float_as_int(x);
-  const int ix = hx & 0x7fffffff;
-  int id;
-  if (ix >= 0x4c000000) {
-    if (ix > 0x7f800000) return x + x;
-    return hx > 0 ? hi[3] + lo[3] : -hi[3] - lo[3];
-  }
-  if (ix < 0x3ee00000) {
-    if (ix < 0x31000000) return x;
-    id = -1;
-  } else {
-    x = fabsf(x);
-    if (ix < 0x3f980000) {
-      if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
-      else                 { id = 1; x = (x - 1.0f) / (x + 1.0f); }
-    } else {
-      if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
-      else                 { id = 3; x = -1.0f / x; }
-    }
-  }
-  const float z = x * x;
-  const float w = z * z;
-  const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f + w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
-  const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f + w * -3.6531571299e-02f))));
-  if (id < 0) return x - x * (s1 + s2);
-  const float r = hi[id] - ((x * (s1 + s2) - lo[id]) - x);
-  return hx < 0 ? -r : r;
-}
-
-__device__ __forceinline__ float atan2f_port(float y, float x) {
-  const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
-  const int hx = __float_as_int(x), hy = __float_as_int(y);
-  const int ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
-  if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
-  if (hx == 0x3f800000) return atanf_port(y);
-  const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
-  if (iy == 0) {
-    if (m < 2) return y;
-    return m == 2 ? pi + tiny : -pi - tiny;
-  }
-  if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
-  if (ix == 0x7f800000) {
-    if (iy == 0x7f800000) {
-      switch (m) { case 0: return pi_o_4 + tiny; case 1: return -pi_o_4 - tiny; case 2: return 3.0f * pi_o_4 + tiny; default: return -3.0f * pi_o_4 - tiny; }
-    }
-    switch (m) { case 0: return 0.0f; case 1: return -0.0f; case 2: return pi + tiny; default: return -pi - tiny; }
-  }
-  if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
-  const int k = (iy - ix) >> 23;
-  float z;
-  if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
-  else if (hx < 0 && k < -60) z = 0.0f;
-  else z = atanf_port(fabsf(y / x));
-  switch (m) {
-    case 0: return z;
-    case 1: return __int_as_float(__float_as_int(z) ^ (int)0x80000000);
-    case 2: return pi - (z - pi_lo);
-    default: return (z - pi_lo) - pi;
-  }
 }
 
 // 64-bit wave shuffles

@@ -75,15 +75,10 @@ __global__ __launch_bounds__(1024) void k_find_ends(RegArgs a, const int* __rest
   }
 }
 
-// Ring id of a kept point (reference src/scanRegistration.cpp:166-205); -1 = rejected.
-__device__ __forceinline__ int ring_of(const float4& p, int R, int ring_from_field) {
+// Ring id from the elevation angle in degrees, exactly the expressions of reference src/scanRegistration.cpp:169-205; -1 = rejected.
+// Monotone (non-increasing ring id) in the angle over one contiguous accepted interval, which is what the fast path below relies on.
+__device__ __forceinline__ int ring_from_angle(float angle, int R) {
   int scanID;
-  if (ring_from_field) {
-    scanID = (int)p.w;
-    return (scanID > R - 1 || scanID < 0) ? -1 : scanID;
-  }
-  // `atan` / `sqrt` unqualified at :166 -> double overloads on the pinned toolchain; sqrt's argument is an f32 sum.
-  const float angle = (float)(atan((double)p.z / sqrt((double)(p.x * p.x + p.y * p.y))) * 180 / M_PI);
   if (R == 16) {
     scanID = (int)((double)((angle + 15) / 2) + 0.5);
     return (scanID > R - 1 || scanID < 0) ? -1 : scanID;
@@ -96,6 +91,32 @@ __device__ __forceinline__ int ring_of(const float4& p, int R, int ring_from_fie
   else scanID = R / 2 + (int)((-8.83 - (double)angle) * 2.0 + 0.5);
   if ((double)angle > 2 || (double)angle < -24.33 || scanID > 50 || scanID < 0) return -1;
   return scanID;
+}
+// Ring id of a kept point (reference src/scanRegistration.cpp:166-205); -1 = rejected.
+// `atan` / `sqrt` are unqualified at :166 -> double overloads on the pinned toolchain (sqrt's argument is an f32 sum), the result is
+// rounded to float.  The f64 atan is the most expensive thing this kernel does, and its 16 extra digits only matter within ~1e-6
+// degrees of a ring boundary: the angle is first evaluated in f32 (z * rsq(x^2 + y^2) through a degree-6 minimax polynomial of
+// atan(t) / t on |t| <= 0.65, i.e. elevations up to 33 degrees; total error < 2e-5 degrees), and if the ring decision is the same
+// 2e-4 degrees below and above it — the decision is monotone in the angle — that IS the decision of the exact angle.  Otherwise
+// (0.1 % of the points, and anything steeper than 33 degrees) the exact f64 expression decides.
+#ifndef ALOAM_RING_F64_ONLY
+#define ALOAM_RING_F64_ONLY 0   // A/B builds: 1 = always the f64 expression (round 1)
+#endif
+__device__ __forceinline__ int ring_of(const float4& p, int R, int ring_from_field) {
+  if (ring_from_field) {
+    const int scanID = (int)p.w;
+    return (scanID > R - 1 || scanID < 0) ? -1 : scanID;
+  }
+  const float s2 = p.x * p.x + p.y * p.y;
+  if (!ALOAM_RING_F64_ONLY) {
+    const float t = p.z * __frsqrt_rn(s2), u = t * t;
+    const float poly = 1.0f + u * (-0.3333319425582886f + u * (0.19994600117206573f + u * (-0.1420508623123169f + u * (0.10522426664829254f + u * (-0.06763934344053268f + u * 0.025188861414790154f)))));
+    const float fast = t * poly * 57.29577951f;
+    const int lo = ring_from_angle(fast - 2e-4f, R), hi = ring_from_angle(fast + 2e-4f, R);
+    if (lo == hi && fabsf(t) <= 0.65f) return lo;                             // NaN / inf fail the second test
+  }
+  const float angle = (float)(atan((double)p.z / sqrt((double)s2)) * 180 / M_PI);
+  return ring_from_angle(angle, R);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -183,58 +204,69 @@ __global__ __launch_bounds__(1024) void k_ring_offsets(RegArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
+// Stable compaction into the ring-ordered cloud.  A workgroup owns 1024 consecutive points = 4 rounds of 256; the order of the
+// points of one ring inside the block is (round, wave, lane).  All four rounds are ranked first (wave ballots), one LDS pass turns
+// the 16 (round, wave) counts of every ring into offsets, then every point is stored: three barriers per block, and the loads of
+// all four rounds are in flight together.
 __global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
   const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const SeqMeta m = a.meta[b];
   const int n = m.n_in < a.cap ? m.n_in : a.cap;
   if (blk * kBlockPts >= n) return;
   const char* in = a.in + (long long)b * a.seq_stride;
-  __shared__ int s_base[kMaxRings];
-  __shared__ int s_wcnt[4][kMaxRings];
-  if (tid < a.R) s_base[tid] = a.ringstart[b * (a.R + 1) + tid] + a.blockoff[((long long)b * a.NB + blk) * a.R + tid];
-  for (int q = tid; q < 4 * kMaxRings; q += 256) (&s_wcnt[0][0])[q] = 0;
-  __syncthreads();
-  const float startOri = m.start_ori, endOri = m.end_ori;
-#pragma unroll 1
+  __shared__ int s_cnt[16][kMaxRings];        // [round * 4 + wave][ring]: points of that ring in that wave's round -> offsets
+  for (int q = tid; q < 16 * kMaxRings; q += 256) (&s_cnt[0][0])[q] = 0;
+  int ring[4], rank[4];
+  float4 p[4];
+  float ori[4];
+#pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = blk * kBlockPts + k * 256 + tid;
-    const int ring = (i < n) ? (int)a.ringid[(long long)b * a.cap + i] : -1;
+    ring[k] = (i < n) ? (int)a.ringid[(long long)b * a.cap + i] : -1;
+    p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ori[k] = 0.f;
+    if (ring[k] >= 0) { p[k] = load_point(in, i, a.pt_stride); ori[k] = a.ori[(long long)b * a.cap + i]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
     // rank among the same-ring lanes of this wave (stable: lower lane = earlier point)
-    int rank = 0;
-    unsigned long long todo = __ballot(ring >= 0);
+    rank[k] = 0;
+    unsigned long long todo = __ballot(ring[k] >= 0);
     while (todo) {
       const int leader = __ffsll((long long)todo) - 1;
-      const int r = __shfl(ring, leader, 64);
-      const unsigned long long same = __ballot(ring == r);
-      if (ring == r) rank = __popcll(same & ((1ull << lane) - 1ull));
-      if (lane == leader) s_wcnt[wave][r] = __popcll(same);
+      const int r = __shfl(ring[k], leader, 64);
+      const unsigned long long same = __ballot(ring[k] == r);
+      if (ring[k] == r) rank[k] = __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) s_cnt[k * 4 + wave][r] = __popcll(same);
       todo &= ~same;
     }
-    __syncthreads();
-    if (ring >= 0) {
-      int pos = s_base[ring] + rank;
-      for (int w = 0; w < wave; ++w) pos += s_wcnt[w][ring];
-      const float4 p = load_point(in, i, a.pt_stride);
-      float ori = a.ori[(long long)b * a.cap + i];
-      if (i <= m.half_idx) {                                                                    // !halfPassed when visited
-        if ((double)ori < (double)startOri - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
-        else if ((double)ori > (double)startOri + M_PI * 3 / 2) ori = (float)((double)ori - 2 * M_PI);
-      } else {                                                                                  // :225-236
-        ori = (float)((double)ori + 2 * M_PI);
-        if ((double)ori < (double)endOri - M_PI * 3 / 2) ori = (float)((double)ori + 2 * M_PI);
-        else if ((double)ori > (double)endOri + M_PI / 2) ori = (float)((double)ori - 2 * M_PI);
-      }
-      const float relTime = (ori - startOri) / (endOri - startOri);                             // :238
-      const float inten = (float)((double)ring + 0.1 * (double)relTime);                        // :239, scanPeriod 0.1
-      a.cloud[(long long)b * a.cap + pos] = make_float4(p.x, p.y, p.z, inten);
+  }
+  __syncthreads();
+  if (tid < a.R) {                             // exclusive offsets over the 16 (round, wave) slots, on top of the block's base
+    int run = a.ringstart[b * (a.R + 1) + tid] + a.blockoff[((long long)b * a.NB + blk) * a.R + tid];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const int c = s_cnt[q][tid]; s_cnt[q][tid] = run; run += c; }
+  }
+  __syncthreads();
+  const float startOri = m.start_ori, endOri = m.end_ori;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (ring[k] < 0) continue;
+    const int i = blk * kBlockPts + k * 256 + tid;
+    const int pos = s_cnt[k * 4 + wave][ring[k]] + rank[k];
+    float o = ori[k];
+    if (i <= m.half_idx) {                                                                    // !halfPassed when visited
+      if ((double)o < (double)startOri - M_PI / 2) o = (float)((double)o + 2 * M_PI);
+      else if ((double)o > (double)startOri + M_PI * 3 / 2) o = (float)((double)o - 2 * M_PI);
+    } else {                                                                                  // :225-236
+      o = (float)((double)o + 2 * M_PI);
+      if ((double)o < (double)endOri - M_PI * 3 / 2) o = (float)((double)o + 2 * M_PI);
+      else if ((double)o > (double)endOri + M_PI / 2) o = (float)((double)o - 2 * M_PI);
     }
-    __syncthreads();
-    if (tid < a.R) {
-      int add = 0;
-      for (int w = 0; w < 4; ++w) { add += s_wcnt[w][tid]; s_wcnt[w][tid] = 0; }
-      s_base[tid] += add;
-    }
-    __syncthreads();
+    const float relTime = (o - startOri) / (endOri - startOri);                               // :238
+    const float inten = (float)((double)ring[k] + 0.1 * (double)relTime);                     // :239, scanPeriod 0.1
+    a.cloud[(long long)b * a.cap + pos] = make_float4(p[k].x, p[k].y, p[k].z, inten);
   }
 }
 

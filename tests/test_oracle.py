@@ -408,3 +408,15 @@ def test_lstsq_5x3_matches_numpy(O):
         x = O.lstsq_5x3(pts, b)
         ref = np.linalg.lstsq(pts, b, rcond=None)[0]
         assert np.allclose(x, ref, rtol=1e-8, atol=1e-10), (x, ref)
+
+
+def test_device_atan_restatement_matches_glibc_bit_for_bit():
+    """a-loam_amd/csrc/aloam_atan.hpp (branch-free FDLIBM atanf / atan2f, what k_classify evaluates at reference
+    src/scanRegistration.cpp:141-142,208) compiled for the host with -ffp-contract=off, against this box's glibc: ~13 million
+    values incl. every boundary of the argument reduction and the special cases."""
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
+    r = subprocess.run(["make", "-C", host, "build/test_atan_port"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(host, "build", "test_atan_port")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:]
