@@ -449,33 +449,19 @@ __global__ __launch_bounds__(256) void k_transform_queries(OdomArgs a) {
 // The kernel is a chain of dependent memory round trips per query (bucket bounds -> bucket entries, twice), so everything
 // that does not depend on a search result is loaded up front and nothing is fetched by index afterwards: grid entries
 // carry their ring key, and the lanes that saw the winners store the record fields themselves.
-#ifndef ALOAM_ASSOC_WAVES
-#define ALOAM_ASSOC_WAVES 1     // query waves per workgroup: measured 1: 1.47 ms, 2: 1.53, 4: 1.63, 8: 1.90 (planar class, batch 512) - single-wave groups refill freed SIMD slots soonest
-#endif
-constexpr int kAssocWaves = ALOAM_ASSOC_WAVES;
+// Launch geometry: one single-wave workgroup per query slot.  Measured at batch 512 (planar class, both launches): 8 waves per
+// workgroup 1.90 ms, 4: 1.63, 2: 1.53, 1: 1.47 — a freed SIMD slot is refilled soonest when nothing else has to retire with it.
+// Persistent waves (exactly the resident number, each walking through 1 / W of the queries of its XCD's sequences) were measured
+// too: 1.84 ms — the loop carries 75 VGPRs instead of 64 (6 waves per SIMD instead of 8) and the kernel lives off occupancy.
 template <bool PLANE, bool DISTORT>
-__global__ __launch_bounds__(64 * kAssocWaves) void k_associate(OdomArgs a) {
-  // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs by linear id and every XCD has its
-  // own 4 MiB L2.  The grids of one sequence (~1.5 MB) are shared by all workgroups of that sequence, so the linear id
-  // is re-mapped such that XCD x works through sequences x, x+8, x+16, ...: each L2 holds a few sequences' grids
-  // instead of thrashing on all of them.  (Pure placement: any mapping gives the same result.)
-  const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, slot = L >> 3;
-  const int b = (slot / (int)gridDim.x) * 8 + xcd, lane = threadIdx.x & 63;
-  if (b >= a.B) return;
+__device__ __forceinline__ void associate_one(const OdomArgs& a, int b, int qi, const SeqMeta& m, const GridView& g, int lane, int* row) {
   constexpr int kSweep = PLANE ? 3 : 2;
-  __shared__ int s_row[kAssocWaves][kSweep * 64];
-  int* row = s_row[threadIdx.x >> 6];
-  const int qi = (slot % (int)gridDim.x) * kAssocWaves + (threadIdx.x >> 6);
   const int qcap = PLANE ? a.R * 24 : a.R * 12;
   const float4* Q = (PLANE ? a.flat : a.sharp) + (long long)b * qcap;
-  const float4 raw = Q[qi < qcap ? qi : qcap - 1];                      // issued together with the scalar loads below
-  const float4 sel = ((PLANE ? a.sel_flat : a.sel_sharp) + (long long)b * qcap)[qi < qcap ? qi : qcap - 1];   // k_transform_queries
-  const SeqMeta m = a.meta[b];
-  const GridView g = grid_view(a, b, PLANE ? 1 : 0);
+  const float4 raw = Q[qi];
+  const float4 sel = ((PLANE ? a.sel_flat : a.sel_sharp) + (long long)b * qcap)[qi];   // k_transform_queries
   const bool bad = g.flags[0] != 0, unsorted = g.flags[1] != 0;
   const float frac = raw.w - (float)(int)raw.w;                              // relTime of the point (:116)
-  const int nq = PLANE ? m.n_flat : m.n_sharp;
-  if (qi >= nq) return;
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
   const float4* T = PLANE ? a.surf_last + (long long)b * a.cap : a.corner_last + (long long)b * a.R * 120;
   int valid = 0;
@@ -619,7 +605,28 @@ __global__ __launch_bounds__(64 * kAssocWaves) void k_associate(OdomArgs a) {
   }
 }
 
+template <bool PLANE, bool DISTORT>
+__global__ __launch_bounds__(64) void k_associate(OdomArgs a) {
+  // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs by linear id and every XCD has its own 4 MiB L2.
+  // The grids of one sequence (~1.5 MB) are shared by all waves working on that sequence, so the linear id is re-mapped such that
+  // XCD x works through sequences x, x+8, x+16, ...: each L2 holds a few sequences' grids instead of thrashing on all of them.
+  // (Pure placement: any mapping gives the same result.)
+  constexpr int kSweep = PLANE ? 3 : 2;
+  __shared__ int row[kSweep * 64];
+  const int lane = threadIdx.x, L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int qcap = PLANE ? a.R * 24 : a.R * 12;
+  const int b = (slot / qcap) * 8 + xcd, qi = slot % qcap;
+  if (b >= a.B) return;
+  const SeqMeta m = a.meta[b];
+  if (qi >= (PLANE ? m.n_flat : m.n_sharp)) return;
+  associate_one<PLANE, DISTORT>(a, b, qi, m, grid_view(a, b, PLANE ? 1 : 0), lane, row);
+}
+
 // -------------------------------------------------------------------------------------------------------
+#ifndef ALOAM_SOLVE_WAVES
+#define ALOAM_SOLVE_WAVES 2      // waves per sequence in k_solve; measured at batch 512: 1: 0.62 ms, 2: 0.44, 4: 0.53, 8: 0.87 (two launches)
+#endif
+constexpr int kSolveWaves = ALOAM_SOLVE_WAVES, kSolveThreads = 64 * kSolveWaves;
 template <bool WITH_JAC, bool DISTORT>
 __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const double t[3], double* acc, int* n_edge, int* n_plane) {
   const int tid = threadIdx.x;
@@ -627,7 +634,7 @@ __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const doub
   const EdgeRec* E = a.edges + (long long)b * a.R * 12;
   const PlaneRec* P = a.planes + (long long)b * a.R * 24;
   int ne = 0, np = 0;
-  for (int i = tid; i < m.n_sharp; i += 256) {
+  for (int i = tid; i < m.n_sharp; i += kSolveThreads) {
     const EdgeRec e = E[i];
     if (!e.valid) continue;
     ++ne;
@@ -667,7 +674,7 @@ __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const doub
       }
     }
   }
-  for (int i = tid; i < m.n_flat; i += 256) {
+  for (int i = tid; i < m.n_flat; i += kSolveThreads) {
     const PlaneRec p = P[i];
     if (!p.valid) continue;
     ++np;
@@ -704,14 +711,14 @@ __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const doub
 // One workgroup per sequence: the whole ceres::Solve stand-in + pose integration.
 // Every thread runs the (uniform) scalar LM logic redundantly; only the evaluations are distributed.
 template <bool DISTORT>
-__global__ __launch_bounds__(256) void k_solve(OdomArgs a) {
+__global__ __launch_bounds__(kSolveThreads) void k_solve(OdomArgs a) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  __shared__ double s_red[4 * 28];
+  __shared__ double s_red[kSolveWaves * 28];
   OdomState& st = a.state[b];
   double q[4] = {st.para_q[0], st.para_q[1], st.para_q[2], st.para_q[3]};
   double t[3] = {st.para_t[0], st.para_t[1], st.para_t[2]};
 
-  const LmResult lm = lm_solve_block([&](bool with_jac, const double* qq, const double* tt, double* acc, int* ne, int* np) {
+  const LmResult lm = lm_solve_block<kSolveWaves>([&](bool with_jac, const double* qq, const double* tt, double* acc, int* ne, int* np) {
     if (with_jac) evaluate<true, DISTORT>(a, b, qq, tt, acc, ne, np); else evaluate<false, DISTORT>(a, b, qq, tt, acc, ne, np);
   }, q, t, a.lm_max_iterations, s_red);
   const int n_edges = lm.n_a, n_planes = lm.n_b, iterations = lm.iterations, successful = lm.successful, termination = lm.termination;
@@ -768,7 +775,7 @@ void launch_transform_queries(const OdomArgs& a, hipStream_t s) {
 }
 void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
-  const dim3 grid((max_queries + kAssocWaves - 1) / kAssocWaves, by), block(64 * kAssocWaves);
+  const dim3 grid((unsigned)(max_queries * by)), block(64);
   if (a.distortion) {
     if (plane) hipLaunchKernelGGL((k_associate<true, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_associate<false, true>), grid, block, 0, s, a);
@@ -778,8 +785,8 @@ void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_
   }
 }
 void launch_solve(const OdomArgs& a, hipStream_t s) {
-  if (a.distortion) hipLaunchKernelGGL(k_solve<true>, dim3(a.B), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(k_solve<false>, dim3(a.B), dim3(256), 0, s, a);
+  if (a.distortion) hipLaunchKernelGGL(k_solve<true>, dim3(a.B), dim3(kSolveThreads), 0, s, a);
+  else hipLaunchKernelGGL(k_solve<false>, dim3(a.B), dim3(kSolveThreads), 0, s, a);
 }
 
 }  // namespace aloam
