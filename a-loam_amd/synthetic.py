@@ -136,10 +136,15 @@ def trajectory(n_frames: int, step: float = 1.0, radius: float = 30.0, seed: int
 
 
 def render_scan(world: World, model: SensorModel, R: torch.Tensor, t: torch.Tensor, noise_sigma: float,
-                generator: torch.Generator | None = None, nan_fraction: float = 0.0) -> torch.Tensor:
+                generator: torch.Generator | None = None, nan_fraction: float = 0.0, rough: bool = False) -> torch.Tensor:
     """Ray-cast one sweep.  Returns float32 [N, 4] (x, y, z, field) in the SENSOR frame and scan order; the 4th
     float is the ring index for ROWS128 and 0 otherwise.  Rays without a return are dropped (as a real
-    driver does); `nan_fraction` replaces that share of the returns by NaN to exercise the NaN filter."""
+    driver does); `nan_fraction` replaces that share of the returns by NaN to exercise the NaN filter.
+
+    `rough` makes the sweep irregular the way recorded KITTI sweeps are: 7 % of the rays return nothing at random, every ring loses
+    one contiguous arc of its own length (rings of unequal length), a tenth of the azimuth range is "vegetation" (range noise of
+    0.3 m: corner candidates everywhere), and a few returns are repeated verbatim 2 .. 14 times (runs of identical points give
+    exactly equal — mostly zero — curvatures, i.e. ties in the sort of src/scanRegistration.cpp:288)."""
     dev = model.dirs.device
     dt = torch.float64
     R = R.to(dev, dt)
@@ -196,17 +201,44 @@ def render_scan(world: World, model: SensorModel, R: torch.Tensor, t: torch.Tens
     else:
         noise = torch.zeros_like(best)
     rng = best + noise_sigma * noise
+    if rough:
+        assert generator is not None
+        gdev = generator.device
+        n_ray = best.shape[0]
+        cols = model.columns
+        # position of every ray on its ring (0 .. columns-1), whatever the message order is
+        ring = model.ring.to(torch.long)
+        col = torch.zeros(n_ray, dtype=torch.long, device=dev)
+        order = torch.argsort(ring, stable=True)
+        col[order] = torch.arange(n_ray, device=dev) % cols if n_ray == model.n_scans * cols else torch.arange(n_ray, device=dev) % cols
+        u = torch.rand(n_ray, generator=generator, dtype=dt, device=gdev).to(dev)
+        valid = valid & (u > 0.07)                                              # random no-returns
+        arc0 = (torch.rand(model.n_scans, generator=generator, dtype=dt, device=gdev).to(dev) * cols).to(torch.long)
+        arcl = (torch.rand(model.n_scans, generator=generator, dtype=dt, device=gdev).to(dev) * 0.04 * cols + 4).to(torch.long)
+        d_arc = (col - arc0[ring]) % cols
+        valid = valid & (d_arc >= arcl[ring])                                    # one missing arc per ring
+        veg0 = int(torch.rand(1, generator=generator, dtype=dt, device=gdev).item() * cols)
+        veg = ((col - veg0) % cols) < cols // 10
+        rough_noise = torch.randn(n_ray, generator=generator, dtype=dt, device=gdev).to(dev)
+        rng = torch.where(veg & (ring % 3 != 0), rng + 0.3 * rough_noise, rng)
     pts = (model.dirs * rng[:, None]).to(torch.float32)
     field = model.ring.to(torch.float32) if model.ring_from_field else torch.zeros(pts.shape[0], dtype=torch.float32, device=dev)
     out = torch.cat([pts, field[:, None]], dim=1)
     if nan_fraction > 0 and generator is not None:
         drop = torch.rand(best.shape, generator=generator, dtype=dt, device=generator.device).to(dev) < nan_fraction
         out[drop, :3] = float("nan")
-    return out[valid].contiguous()
+    out = out[valid].contiguous()
+    if rough and out.shape[0] > 64:
+        n_dup = 24
+        pos = (torch.rand(n_dup, generator=generator, dtype=dt, device=generator.device) * (out.shape[0] - 16)).to(torch.long).tolist()
+        run = (torch.rand(n_dup, generator=generator, dtype=dt, device=generator.device) * 13 + 2).to(torch.long).tolist()
+        for i, l in zip(pos, run):
+            out[i + 1:i + l, :3] = out[i, :3]                                    # the same return repeated (the ring field stays)
+    return out
 
 
 def make_sequence(model_name: str, n_frames: int, seed: int, noise_sigma: float | None = None, device="cpu",
-                  world_seed: int | None = None, step: float = 1.0, nan_fraction: float = 0.0, columns: int | None = None):
+                  world_seed: int | None = None, step: float = 1.0, nan_fraction: float = 0.0, columns: int | None = None, rough: bool = False):
     """Returns (scans: list of float32 [N_i,4] tensors, R [n,3,3], t [n,3], model)."""
     model = sensor_model(model_name, columns=columns, device=device)
     world = make_world(seed if world_seed is None else world_seed).to(device)
@@ -214,7 +246,7 @@ def make_sequence(model_name: str, n_frames: int, seed: int, noise_sigma: float 
         noise_sigma = 0.01 if model_name == "VLP-16" else 0.02
     R, t = trajectory(n_frames, step=step, seed=seed, start_angle=0.37 * seed)
     gen = torch.Generator(device=device).manual_seed(77 + seed)
-    scans = [render_scan(world, model, R[k], t[k], noise_sigma, gen, nan_fraction) for k in range(n_frames)]
+    scans = [render_scan(world, model, R[k], t[k], noise_sigma, gen, nan_fraction, rough) for k in range(n_frames)]
     return scans, R, t, model
 
 

@@ -86,7 +86,8 @@ def test_live_reference_build_matches_oracle(O, sequence):
     if not os.path.isdir(os.path.join(ref_py.REFERENCE_ROOT, "src")):
         pytest.skip("reference sources not present on this box; the committed ref_*.npz fixtures cover it")
     assert ref_py.build()
-    for name, frames, seed, kw in (("VLP-16", 3, 21, {"columns": 900}), ("HDL-32", 2, 22, {"columns": 500}), ("HDL-64", 3, 23, {"columns": 512})):
+    for name, frames, seed, kw in (("VLP-16", 3, 21, {"columns": 900}), ("HDL-32", 2, 22, {"columns": 500}), ("HDL-64", 3, 23, {"columns": 512}),
+                                   ("HDL-64", 3, 24, {"columns": 1024, "rough": True}), ("VLP-16", 3, 25, {"columns": 900, "rough": True})):   # rough: ragged rings, dropouts, curvature ties
         scans, R, t, model = sequence(name, frames, seed=seed, **kw)
         reg = ref_py.scan_registration(scans, model.n_scans, model.min_range)
         odo = ref_py.laser_odometry(reg)

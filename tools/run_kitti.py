@@ -26,12 +26,20 @@ R_TRANSFORM = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], float)
 
 
 def read_times(path):
-    return [float(l) for l in open(path) if l.strip()]
+    """times.txt, one stamp per line, parsed like `stof(line)` (reference src/kittiHelper.cpp:88): single precision."""
+    return [float(np.float32(l)) for l in open(path) if l.strip()]
+
+
+def read_lidar(path):
+    """One velodyne/%06d.bin: float32 x, y, z, reflectance per point (reference src/kittiHelper.cpp:25-35 read_lidar_data)."""
+    return np.fromfile(path, dtype=np.float32).reshape(-1, 4)
 
 
 def read_gt(path):
-    """-> (N,3,3) rotations and (N,3) translations in the /camera_init convention of kittiHelper.cpp:104-107."""
-    P = np.loadtxt(path).reshape(-1, 3, 4)
+    """-> (N,3,3) rotations and (N,3) translations in the /camera_init convention of kittiHelper.cpp: every entry goes through
+    `stof` (:95-102, single precision), then q = q_transform * q_w_i and t = q_transform * t (:104-107) with
+    R_transform = [0 0 1; -1 0 0; 0 -1 0] (:78-80)."""
+    P = np.loadtxt(path, dtype=np.float32, ndmin=2).astype(np.float64).reshape(-1, 3, 4)
     return np.einsum("ij,njk->nik", R_TRANSFORM, P[:, :, :3]), P[:, :, 3] @ R_TRANSFORM.T
 
 
@@ -79,7 +87,7 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     odo, mapped = [], []
     for k, stamp in enumerate(times):
-        pts = np.fromfile(os.path.join(args.dataset, "velodyne", "sequences", args.seq, "velodyne", f"{k:06d}.bin"), dtype=np.float32).reshape(-1, 4)
+        pts = read_lidar(os.path.join(args.dataset, "velodyne", "sequences", args.seq, "velodyne", f"{k:06d}.bin"))
         gpu.scan_register(pts)
         gpu.odometry_step()
         p = gpu.pose()
