@@ -20,6 +20,7 @@ HEADER_PATH = os.path.join(_ROOT, "include", "aloam_mi355x.h")
 CLOUD_FULL, CLOUD_SHARP, CLOUD_LESS_SHARP, CLOUD_FLAT, CLOUD_LESS_FLAT, CLOUD_CORNER_LAST, CLOUD_SURF_LAST = range(7)
 E_ARG, E_SCAN_LINES, E_EMPTY, E_CAPACITY, E_HIP, E_STATE = -1, -2, -3, -4, -5, -6
 MAP_REGISTERED, MAP_CORNER_STACK, MAP_SURF_STACK = 2, 3, 4
+STAGE_REGISTRATION, STAGE_ODOMETRY, STAGE_MAPPING, STAGE_ALL = 1, 2, 4, 7
 MAP_INFO_KEYS = ("cenW", "cenH", "cenD", "frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack",
                  "corner_num0", "corner_num1", "surf_num0", "surf_num1", "lm_iterations0", "lm_iterations1", "termination0", "compactions")
 
@@ -81,6 +82,7 @@ def lib():
         vp, ip = C.c_void_p, C.POINTER(C.c_int)
         L.aloam_default_config.argtypes = [C.POINTER(AloamConfig)]; L.aloam_default_config.restype = None
         L.aloam_create.argtypes = [C.POINTER(AloamConfig), C.POINTER(vp)]
+        L.aloam_create_stages.argtypes = [C.POINTER(AloamConfig), C.c_int, C.POINTER(vp)]
         L.aloam_destroy.argtypes = [vp]; L.aloam_destroy.restype = None
         L.aloam_last_error.argtypes = [vp]; L.aloam_last_error.restype = C.c_char_p
         L.aloam_stream.argtypes = [vp]; L.aloam_stream.restype = vp
@@ -137,7 +139,7 @@ class Aloam:
     `gpu.scan_register(x)` next to `oracle.scan_register(x)`."""
 
     def __init__(self, n_scans=64, min_range=5.0, ring_from_field=False, batch=1, max_points=140000, max_ring_points=4107,
-                 device=0, lm_max_iterations=4, outer_iterations=2, distortion=False):
+                 device=0, lm_max_iterations=4, outer_iterations=2, distortion=False, stages=STAGE_ALL):
         L = lib()
         cfg = AloamConfig()
         L.aloam_default_config(C.byref(cfg))
@@ -147,7 +149,7 @@ class Aloam:
         cfg.distortion = int(distortion)
         self.cfg, self.batch, self.n_scans, self.max_points = cfg, batch, n_scans, max_points
         h = C.c_void_p()
-        rc = L.aloam_create(C.byref(cfg), C.byref(h))
+        rc = L.aloam_create_stages(C.byref(cfg), int(stages), C.byref(h))
         self.h = h
         if rc != 0:
             msg = L.aloam_last_error(h).decode() if h else "allocation failed"

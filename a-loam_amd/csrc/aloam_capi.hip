@@ -31,6 +31,7 @@ constexpr int kNinSlots = 8;
 
 struct aloam_ctx {
   aloam_config cfg{};
+  int stages = ALOAM_STAGE_ALL;      // which stages this context has buffers for (aloam_create_stages)
   int B = 0, cap = 0, R = 0, NB = 0, npad = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -197,6 +198,7 @@ int fetch_meta(aloam_ctx* c, int seq, SeqMeta* m) {
 // debug_arrays: also write cloudCurvature / cloudLabel (the per-point entry points aloam_get_curvature / aloam_get_labels);
 // the throughput entries (aloam_process_device / aloam_process_host) leave those 5 bytes per point out.
 int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, const int* n_in, int stride_bytes, int slot = -1, bool debug_arrays = true) {
+  if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
   if (stride_bytes < 16 || (stride_bytes & 3)) { c->err = "stride_bytes must be >= 16 and a multiple of 4"; return ALOAM_E_ARG; }
   for (int b = 0; b < c->B; ++b) {
     if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
@@ -241,12 +243,16 @@ void aloam_default_config(aloam_config* cfg) {
   cfg->distortion = 0;
 }
 
-int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
+int aloam_create(const aloam_config* cfg, aloam_ctx** out) { return aloam_create_stages(cfg, ALOAM_STAGE_ALL, out); }
+
+int aloam_create_stages(const aloam_config* cfg, int stages, aloam_ctx** out) {
   if (!cfg || !out) return ALOAM_E_ARG;
   *out = nullptr;
   aloam_ctx* c = new aloam_ctx();
   c->cfg = *cfg;
+  c->stages = stages;
   *out = c;   // returned even on failure so that aloam_last_error() works; caller destroys it
+  if ((stages & ~ALOAM_STAGE_ALL) || !(stages & ALOAM_STAGE_ALL)) { c->err = "stages must be a non-empty combination of ALOAM_STAGE_*"; return ALOAM_E_ARG; }
   if (cfg->batch < 1 || cfg->max_points < 32 || cfg->max_points > 400000 || cfg->lm_max_iterations < 0 || cfg->outer_iterations < 1 ||
       cfg->outer_iterations > 64) { c->err = "bad configuration value"; return ALOAM_E_ARG; }
   if (!cfg->ring_from_field && cfg->n_scans != 16 && cfg->n_scans != 32 && cfg->n_scans != 64) {
@@ -272,38 +278,51 @@ int aloam_create(const aloam_config* cfg, aloam_ctx** out) {
   int rc = 0;
   HIP_TRY(c, hipHostMalloc((void**)&c->h_nin, sizeof(int) * B * kNinSlots, hipHostMallocDefault));
   for (hipEvent_t& e : c->nin_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const bool reg = stages & ALOAM_STAGE_REGISTRATION, odo = stages & ALOAM_STAGE_ODOMETRY, map = stages & ALOAM_STAGE_MAPPING;
+  // hash tables of the correspondence search sized by the clouds they index (power of two; the surf table must fit k_build_grids' LDS)
+  c->grid_H[0] = R > 64 ? 8192 : 4096;
+  c->grid_H[1] = cap > 160000 ? 32768 : 16384;
   if ((rc = dmalloc(c, &c->d_nin, B))) return rc;
   if ((rc = dmalloc(c, &c->d_meta, B))) return rc;
-  if ((rc = dmalloc(c, &c->d_ringid, B * cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_ori, B * cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_hist, B * NB * R))) return rc;
-  if ((rc = dmalloc(c, &c->d_blockoff, B * NB * R))) return rc;
-  if ((rc = dmalloc(c, &c->d_ringstart, B * (R + 1)))) return rc;
-  if ((rc = dmalloc(c, &c->d_cloud, B * cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_curv, B * cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_label, B * cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_lookback, B * 4 * R))) return rc;
-  if ((rc = dmalloc(c, &c->d_sharp, B * R * 12))) return rc;
-  if ((rc = dmalloc(c, &c->d_flat, B * R * 24))) return rc;
+  if ((rc = dmalloc(c, &c->d_state, B))) return rc;
+  if ((rc = dmalloc(c, &c->d_cloud, B * cap))) return rc;                    // /velodyne_cloud_2 -> _3 -> mapping's full-resolution input
+  if (reg) {                                                                 // working set of scan registration
+    if ((rc = dmalloc(c, &c->d_ringid, B * cap))) return rc;
+    if ((rc = dmalloc(c, &c->d_ori, B * cap))) return rc;
+    if ((rc = dmalloc(c, &c->d_hist, B * NB * R))) return rc;
+    if ((rc = dmalloc(c, &c->d_blockoff, B * NB * R))) return rc;
+    if ((rc = dmalloc(c, &c->d_ringstart, B * (R + 1)))) return rc;
+    if ((rc = dmalloc(c, &c->d_curv, B * cap))) return rc;
+    if ((rc = dmalloc(c, &c->d_label, B * cap))) return rc;
+    if ((rc = dmalloc(c, &c->d_lookback, B * 4 * R))) return rc;
+  }
+  if (reg || odo) {
+    if ((rc = dmalloc(c, &c->d_sharp, B * R * 12))) return rc;
+    if ((rc = dmalloc(c, &c->d_flat, B * R * 24))) return rc;
+  }
   for (int k = 0; k < 2; ++k) {
+    // [cur = 0] receives the sweep being registered, [1] is what a mapping-only context is handed as the "last" clouds; odometry flips between both
+    if (!(odo || (k == 0 && reg) || (k == 1 && map))) continue;
     if ((rc = dmalloc(c, &c->d_less_sharp[k], B * R * 120))) return rc;
     if ((rc = dmalloc(c, &c->d_less_flat[k], B * cap))) return rc;
   }
-  if ((rc = dmalloc(c, &c->d_state, B))) return rc;
-  for (int k = 0; k < 2; ++k) {
-    const size_t per = k == 0 ? R * 120 : cap;
-    if ((rc = dmalloc(c, &c->d_grid_sorted3[k], B * per))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_sorted2[k], B * per))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_start3[k], B * (c->grid_H[k] + 1)))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_start2[k], B * (c->grid_H[k] + 1)))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_sorted3c[k], B * per))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_start3c[k], B * (c->grid_H[k] + 1)))) return rc;
-    if ((rc = dmalloc(c, &c->d_grid_flags[k], B * 4))) return rc;
+  if (odo) {
+    for (int k = 0; k < 2; ++k) {
+      const size_t per = k == 0 ? R * 120 : cap;
+      if ((rc = dmalloc(c, &c->d_grid_sorted3[k], B * per))) return rc;
+      if ((rc = dmalloc(c, &c->d_grid_sorted2[k], B * per))) return rc;
+      if ((rc = dmalloc(c, &c->d_grid_start3[k], B * (c->grid_H[k] + 1)))) return rc;
+      if ((rc = dmalloc(c, &c->d_grid_start2[k], B * (c->grid_H[k] + 1)))) return rc;
+      if ((rc = dmalloc(c, &c->d_grid_sorted3c[k], B * per))) return rc;
+      if ((rc = dmalloc(c, &c->d_grid_start3c[k], B * (c->grid_H[k] + 1)))) return rc;
+      if ((rc = dmalloc(c, &c->d_grid_flags[k], B * 4))) return rc;
+    }
+    if ((rc = dmalloc(c, &c->d_edges, B * R * 12))) return rc;
+    if ((rc = dmalloc(c, &c->d_planes, B * R * 24))) return rc;
+    if ((rc = dmalloc(c, &c->d_sel_sharp, B * R * 12))) return rc;
+    if ((rc = dmalloc(c, &c->d_sel_flat, B * R * 24))) return rc;
+    if ((rc = prepare_build_grids(c->grid_H[1]))) { c->err = "k_build_grids: dynamic LDS size rejected"; return ALOAM_E_HIP; }
   }
-  if ((rc = dmalloc(c, &c->d_edges, B * R * 12))) return rc;
-  if ((rc = dmalloc(c, &c->d_planes, B * R * 24))) return rc;
-  if ((rc = dmalloc(c, &c->d_sel_sharp, B * R * 12))) return rc;
-  if ((rc = dmalloc(c, &c->d_sel_flat, B * R * 24))) return rc;
   // identity poses (src/laserOdometry.cpp:93-98)
   std::vector<OdomState> init(B);
   std::memset(init.data(), 0, sizeof(OdomState) * B);
@@ -359,8 +378,10 @@ int aloam_synchronize(aloam_ctx* c) {
     int vc[2] = {0, 0};
     HIP_TRY(c, hipMemcpy(ms.data(), c->d_mapseq, sizeof(MapSeq) * c->B, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(vc, c->d_vox_counters, sizeof(vc), hipMemcpyDeviceToHost));
-    if (vc[1]) { c->err = "mapping: voxel-filter scratch too small for the map (raise pool_points) or a cube holds more than 2^" + std::to_string(11 + c->map_cube_levels) + " points"; return ALOAM_E_CAPACITY; }
-    for (int b = 0; b < c->B; ++b) if (ms[b].err & kMapErrPool) { c->err = "sequence " + std::to_string(b) + ": map pool exhausted (raise pool_points)"; return ALOAM_E_CAPACITY; }
+    // both flags describe the LAST mapping step only (reset at its start); the step itself has run: poses and map are valid, the
+    // frame's points that did not fit were left out of the map
+    if (vc[1]) { c->err = "mapping: voxel-filter scratch too small for this frame (raise pool_points)"; return ALOAM_E_CAPACITY; }
+    for (int b = 0; b < c->B; ++b) if (ms[b].err & kMapErrPool) { c->err = "sequence " + std::to_string(b) + ": map pool exhausted in the last step, some points were not inserted (raise pool_points)"; return ALOAM_E_CAPACITY; }
   }
   return ALOAM_OK;
 }
@@ -389,6 +410,7 @@ static int acquire_slab(aloam_ctx* c, size_t need, int* slot_out) {
 int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in, int stride_bytes) {
   DeviceScope device_scope(c);
   if (!c || !scans || !n_in) return ALOAM_E_ARG;
+  if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
   if (stride_bytes < 16) { c->err = "stride_bytes must be >= 16"; return ALOAM_E_ARG; }
   const size_t seq_stride = (size_t)c->cap * stride_bytes;
   for (int b = 0; b < c->B; ++b) if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
@@ -409,6 +431,7 @@ int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in,
 // pageable memory synchronously.  The buffer must stay unmodified until aloam_input_consumed() / aloam_synchronize().
 static int stage_and_register(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes, bool debug_arrays) {
   if (!c || !h_scans || !n_in) return ALOAM_E_ARG;
+  if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
   if (stride_bytes < 16 || (stride_bytes & 3) || seq_stride_bytes < 0) { c->err = "bad stride"; return ALOAM_E_ARG; }
   int nmax = 0;
   for (int b = 0; b < c->B; ++b) {
@@ -456,6 +479,7 @@ int aloam_input_consumed(aloam_ctx* c) {
 int aloam_odometry_step(aloam_ctx* c) {
   DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
+  if (!(c->stages & ALOAM_STAGE_ODOMETRY)) { c->err = "this context was created without ALOAM_STAGE_ODOMETRY"; return ALOAM_E_STATE; }
   if (!c->have_features) { c->err = "aloam_odometry_step before any features were registered / set"; return ALOAM_E_STATE; }
   if (!c->system_inited) {
     c->system_inited = true;                       // first frame: no solve (src/laserOdometry.cpp:267-271)
@@ -489,16 +513,17 @@ int aloam_process_device(aloam_ctx* c, const void* d_scans, long long seq_stride
 // ---- results ---------------------------------------------------------------------------------------------
 static int cloud_ref(aloam_ctx* c, int seq, int which, const SeqMeta& m, const float4** ptr, int* n) {
   const size_t b = seq;
+  auto at = [](const float4* base, size_t off) -> const float4* { return base ? base + off : nullptr; };
   // aloam_odometry_step ends with the reference's pointer swap (src/laserOdometry.cpp:554-560): afterwards the sweep
   // just processed is read through CORNER_LAST / SURF_LAST, exactly like laserCloudCornerLast / laserCloudSurfLast.
   switch (which) {
-    case ALOAM_CLOUD_FULL: *ptr = c->d_cloud + b * c->cap; *n = m.n_cloud; return 0;
-    case ALOAM_CLOUD_SHARP: *ptr = c->d_sharp + b * c->R * 12; *n = m.n_sharp; return 0;
-    case ALOAM_CLOUD_FLAT: *ptr = c->d_flat + b * c->R * 24; *n = m.n_flat; return 0;
-    case ALOAM_CLOUD_LESS_SHARP: *ptr = c->d_less_sharp[c->cur] + b * c->R * 120; *n = m.n_less_sharp; return 0;
-    case ALOAM_CLOUD_LESS_FLAT: *ptr = c->d_less_flat[c->cur] + b * c->cap; *n = m.n_less_flat; return 0;
-    case ALOAM_CLOUD_CORNER_LAST: *ptr = c->d_less_sharp[1 - c->cur] + b * c->R * 120; *n = m.n_corner_last; return 0;
-    case ALOAM_CLOUD_SURF_LAST: *ptr = c->d_less_flat[1 - c->cur] + b * c->cap; *n = m.n_surf_last; return 0;
+    case ALOAM_CLOUD_FULL: *ptr = at(c->d_cloud, b * c->cap); *n = m.n_cloud; return 0;
+    case ALOAM_CLOUD_SHARP: *ptr = at(c->d_sharp, b * c->R * 12); *n = m.n_sharp; return 0;
+    case ALOAM_CLOUD_FLAT: *ptr = at(c->d_flat, b * c->R * 24); *n = m.n_flat; return 0;
+    case ALOAM_CLOUD_LESS_SHARP: *ptr = at(c->d_less_sharp[c->cur], b * c->R * 120); *n = m.n_less_sharp; return 0;
+    case ALOAM_CLOUD_LESS_FLAT: *ptr = at(c->d_less_flat[c->cur], b * c->cap); *n = m.n_less_flat; return 0;
+    case ALOAM_CLOUD_CORNER_LAST: *ptr = at(c->d_less_sharp[1 - c->cur], b * c->R * 120); *n = m.n_corner_last; return 0;
+    case ALOAM_CLOUD_SURF_LAST: *ptr = at(c->d_less_flat[1 - c->cur], b * c->cap); *n = m.n_surf_last; return 0;
   }
   return -1;
 }
@@ -511,6 +536,7 @@ int aloam_cloud_size(aloam_ctx* c, int seq, int which) {
   if ((rc = fetch_meta(c, seq, &m))) return rc;
   const float4* p; int n;
   if (cloud_ref(c, seq, which, m, &p, &n)) { c->err = "unknown cloud id"; return ALOAM_E_ARG; }
+  if (!p) { c->err = "this context holds no such cloud (see aloam_create_stages)"; return ALOAM_E_STATE; }
   return n;
 }
 
@@ -522,6 +548,7 @@ int aloam_get_cloud(aloam_ctx* c, int seq, int which, float* out, int cap_points
   if ((rc = fetch_meta(c, seq, &m))) return rc;
   const float4* p; int n;
   if (cloud_ref(c, seq, which, m, &p, &n)) { c->err = "unknown cloud id"; return ALOAM_E_ARG; }
+  if (!p) { c->err = "this context holds no such cloud (see aloam_create_stages)"; return ALOAM_E_STATE; }
   const int k = n < cap_points ? n : cap_points;
   if (k > 0) HIP_TRY(c, hipMemcpy(out, p, sizeof(float4) * k, hipMemcpyDeviceToHost));
   return n;
@@ -562,6 +589,7 @@ int aloam_set_features(aloam_ctx* c, int seq, const float* sharp, int n_sharp, c
   if (rc) return rc;
   if (n_sharp < 0 || n_sharp > c->R * 12 || n_less_sharp < 0 || n_less_sharp > c->R * 120 || n_flat < 0 || n_flat > c->R * 24 ||
       n_less_flat < 0 || n_less_flat > c->cap) { c->err = "feature cloud larger than the selection rules allow"; return ALOAM_E_CAPACITY; }
+  if (!c->d_sharp || !c->d_less_sharp[c->cur]) { c->err = "this context has no feature buffers (created for the mapping stage only)"; return ALOAM_E_STATE; }
   const size_t b = seq;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (n_sharp) HIP_TRY(c, hipMemcpy(c->d_sharp + b * c->R * 12, sharp, sizeof(float4) * n_sharp, hipMemcpyHostToDevice));
@@ -581,6 +609,7 @@ int aloam_set_last(aloam_ctx* c, int seq, const float* corner_last, int n_corner
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if (n_corner < 0 || n_corner > c->R * 120 || n_surf < 0 || n_surf > c->cap) { c->err = "last cloud too large"; return ALOAM_E_CAPACITY; }
+  if (!c->d_less_sharp[1 - c->cur]) { c->err = "this context has no buffers for the last clouds (created for the registration stage only)"; return ALOAM_E_STATE; }
   const size_t b = seq;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (n_corner) HIP_TRY(c, hipMemcpy(c->d_less_sharp[1 - c->cur] + b * c->R * 120, corner_last, sizeof(float4) * n_corner, hipMemcpyHostToDevice));
@@ -783,6 +812,7 @@ static VoxArgs vox_args(aloam_ctx* c, int n_segs, int levels) {
 int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool_points) {
   DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
+  if (!(c->stages & ALOAM_STAGE_MAPPING)) { c->err = "this context was created without ALOAM_STAGE_MAPPING"; return ALOAM_E_STATE; }
   if (c->map_on) { c->err = "mapping already enabled"; return ALOAM_E_STATE; }
   if (!(line_res > 0.f) || !(plane_res > 0.f) || pool_points < 4096) { c->err = "bad mapping parameters (pool_points >= 4096)"; return ALOAM_E_ARG; }
   const size_t B = c->B, cap = c->cap, R = c->R;
@@ -792,8 +822,8 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   for (int k = 0; k < 2; ++k) { int H = 4096; while (H < (int)pool / 16 && H < (1 << 17)) H <<= 1; c->map_H[k] = H; }   // ~ submap size, not pool size
   c->map_levels = 0;                                       // incoming clouds: up to max_points
   while (((size_t)kVoxTile << c->map_levels) < cap) ++c->map_levels;
-  c->map_cube_levels = 0;                                  // one 50 m cube: up to 65536 points (more is reported as ALOAM_E_CAPACITY)
-  while (((size_t)kVoxTile << c->map_cube_levels) < std::min<size_t>(pool, 65536)) ++c->map_cube_levels;
+  c->map_cube_levels = 0;                                  // one 50 m cube may hold up to the whole pool: enough merge levels for that
+  while (((size_t)kVoxTile << c->map_cube_levels) < pool) ++c->map_cube_levels;   // (levels a cube does not need cost one skipped tile loop each)
   const size_t T = kVoxTile;
   c->map_tile_bound[0] = (int)(B * ((cap + T - 1) / T + (R * 120 + T - 1) / T));
   c->map_tile_bound[1] = (int)(B * (2 * pool / T + 2 * kMapValidMax));
@@ -846,6 +876,7 @@ int aloam_mapping_step(aloam_ctx* c) {
   if (!c) return ALOAM_E_ARG;
   if (!c->map_on) { c->err = "aloam_mapping_step before aloam_mapping_enable"; return ALOAM_E_STATE; }
   const MapArgs a = map_args(c);
+  HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 1, 0, sizeof(int), c->stream));   // capacity flags are per step (k_map_begin clears the per-sequence one)
   { ProfScope p(c, K_MAP_BEGIN); launch_map_begin(a, c->stream); }
   { ProfScope p(c, K_MAP_VOXEL_STACK);                                      // downSizeFilterCorner / Surf on the incoming clouds (:542-550)
     const VoxArgs v = vox_args(c, c->B * 2, c->map_levels);

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void k_map_begin(MapArgs a) {
   MapSeq& ms = a.seq[b];
   __shared__ int s_c[3], s_cen[3];
   if (tid == 0) {
+    ms.err = 0;                                                              // capacity flags describe one step
     const OdomState& od = a.odom[b];
     double qo[4], to[3], qm[4], q[4], rt[3];
     for (int k = 0; k < 4; ++k) { qo[k] = od.q_w[k]; qm[k] = ms.q_wmap_wodom[k]; ms.q_wodom[k] = qo[k]; }

@@ -758,14 +758,12 @@ void launch_advance(SeqMeta* meta, int B, hipStream_t s) { hipLaunchKernelGGL(k_
 
 // -------------------------------------------------------------------------------------------------------
 size_t build_grids_lds_bytes(int H, int R) { return sizeof(int) * ((size_t)H + 1024 + 2 * (R + 8) + 4); }
+// The surf grid needs > 64 KiB of dynamic LDS: the attribute belongs to the function ON the current device; aloam_create sets it
+// once per context (no process-global state).
+int prepare_build_grids(int H_surf) {
+  return hipFuncSetAttribute((const void*)k_build_grids, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_grids_lds_bytes(H_surf, kMaxRings)) == hipSuccess ? 0 : -1;
+}
 void launch_build_grids(const OdomArgs& a, hipStream_t s) {
-  static bool attr_set[64] = {};                    // per device: the attribute belongs to the function ON a device
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {     // the surf grid needs > 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)k_build_grids, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_grids_lds_bytes(a.grid_H_surf, kMaxRings));
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
   hipLaunchKernelGGL(k_build_grids, dim3(ALOAM_BG_SPLIT ? 6 : 2, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
 }
 void launch_transform_queries(const OdomArgs& a, hipStream_t s) {

@@ -114,9 +114,16 @@ static void process() {
     quat_rot(q_wmap_wodom, to, t_guess);
     for (int k = 0; k < 3; ++k) t_guess[k] += t_wmap_wodom[k];
     if (aloam_set_last(g_ctx, 0, corner.data(), nCorner, surf.data(), nSurf) != ALOAM_OK || aloam_set_full_cloud(g_ctx, 0, full.data(), nFull) != ALOAM_OK ||
-        aloam_set_state(g_ctx, 0, id_q, id_t, qo, to) != ALOAM_OK || aloam_mapping_step(g_ctx) != ALOAM_OK || aloam_synchronize(g_ctx) != ALOAM_OK) {
+        aloam_set_state(g_ctx, 0, id_q, id_t, qo, to) != ALOAM_OK || aloam_mapping_step(g_ctx) != ALOAM_OK) {
       ROS_WARN("mapping step failed: %s", aloam_last_error(g_ctx));
       continue;
+    }
+    const int rc_sync = aloam_synchronize(g_ctx);
+    if (rc_sync == ALOAM_E_CAPACITY) ROS_WARN("mapping: %s", aloam_last_error(g_ctx));   // the step has run; only points that did not fit are missing from the map
+    else if (rc_sync != ALOAM_OK) { ROS_WARN("mapping step failed: %s", aloam_last_error(g_ctx)); continue; }
+    {
+      int info[16];
+      if (aloam_get_map_info(g_ctx, 0, info) == ALOAM_OK && !(info[4] > 10 && info[5] > 50)) ROS_WARN("time Map corner and surf num are not enough");   // :554,730-733
     }
     double q_w[4], t_w[3];
     aloam_get_map_pose(g_ctx, 0, q_w, t_w, q_wmap_wodom, t_wmap_wodom);
@@ -183,7 +190,7 @@ int main(int argc, char** argv) {
   cfg.n_scans = n_scans;
   cfg.batch = 1;
   cfg.max_points = 400000;
-  if (aloam_create(&cfg, &g_ctx) != ALOAM_OK || aloam_mapping_enable(g_ctx, lineRes, planeRes, pool_points) != ALOAM_OK) {
+  if (aloam_create_stages(&cfg, ALOAM_STAGE_MAPPING, &g_ctx) != ALOAM_OK || aloam_mapping_enable(g_ctx, lineRes, planeRes, pool_points) != ALOAM_OK) {   // this node hosts stage 3 only
     ROS_ERROR("aloam set-up: %s", g_ctx ? aloam_last_error(g_ctx) : "out of memory");
     return 1;
   }

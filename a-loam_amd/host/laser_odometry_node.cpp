@@ -1,6 +1,7 @@
 // a-loam_amd/host/laser_odometry_node.cpp — the `alaserOdometry` node on top of libaloam_mi355x.so.
 // Same subscriptions, queues, stamp check, publications and frame ids as the reference (src/laserOdometry.cpp:186-263,
 // 508-599); the solve (:265-506) and the cloud swap / kd-tree rebuild (:554-568) are calls into the C ABI.
+#include <chrono>
 #include <cstdio>
 #include <mutex>
 #include <queue>
@@ -38,7 +39,7 @@ int main(int argc, char** argv) {
   cfg.n_scans = n_scans;
   cfg.batch = 1;
   cfg.max_points = 400000;
-  if (aloam_create(&cfg, &g_ctx) != ALOAM_OK) {
+  if (aloam_create_stages(&cfg, ALOAM_STAGE_ODOMETRY, &g_ctx) != ALOAM_OK) {   // this node hosts stage 2 only
     ROS_ERROR("aloam_create: %s", g_ctx ? aloam_last_error(g_ctx) : "out of memory");
     return 1;
   }
@@ -55,7 +56,7 @@ int main(int argc, char** argv) {
   ros::Publisher pubLaserPath = nh.advertise<nav_msgs::Path>("/laser_odom_path", 100);
 
   nav_msgs::Path laserPath;
-  int frameCount = 0;
+  int frameCount = 0, frameTotal = 0;
   ros::Rate rate(100);
   std::vector<float> sharp, lessSharp, flat, lessFlat, full;
 
@@ -69,6 +70,7 @@ int main(int argc, char** argv) {
         printf("unsync messeage!");
         ROS_BREAK();
       }
+      const auto t_whole = std::chrono::steady_clock::now();
       mBuf.lock();
       const int nSharp = aloam_host::msg_to_xyzi(*cornerSharpBuf.front(), &sharp); cornerSharpBuf.pop();
       const int nLessSharp = aloam_host::msg_to_xyzi(*cornerLessSharpBuf.front(), &lessSharp); cornerLessSharpBuf.pop();
@@ -85,6 +87,11 @@ int main(int argc, char** argv) {
       }
       double q_w[4], t_w[3], q_lc[4], t_lc[3];
       aloam_get_pose(g_ctx, 0, q_w, t_w, q_lc, t_lc);
+      aloam_odom_stats st;
+      if (frameTotal > 0 && aloam_get_odom_stats(g_ctx, 0, &st) == ALOAM_OK)
+        for (int it = 0; it < 2; ++it)
+          if (st.corner_corr[it] + st.plane_corr[it] < 10) printf("less correspondence! *************************************************\n");   // :488-491
+      ++frameTotal;
 
       nav_msgs::Odometry laserOdometry;                    // :511-522
       laserOdometry.header.frame_id = "/camera_init";
@@ -110,6 +117,9 @@ int main(int argc, char** argv) {
         pubLaserCloudSurfLast.publish(aloam_host::cloud_msg(g_ctx, ALOAM_CLOUD_SURF_LAST, stamp, "/camera"));
         pubLaserCloudFullRes.publish(aloam_host::xyzi_to_msg(full.data(), nFull, stamp, "/camera"));
       }
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_whole).count();
+      printf("whole laserOdometry time %f ms \n \n", ms);
+      if (ms > 100) ROS_WARN("odometry process over 100ms");   // :593-595
       frameCount++;
     }
     rate.sleep();

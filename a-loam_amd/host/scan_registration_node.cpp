@@ -1,6 +1,7 @@
 // a-loam_amd/host/scan_registration_node.cpp — the `ascanRegistration` node on top of libaloam_mi355x.so.
 // Same node name, parameters, topics, frame ids and stamps as the reference (src/scanRegistration.cpp:461-503); the body
 // of laserCloudHandler (:127-411) is one call into the C ABI.
+#include <chrono>
 #include <cstdio>
 
 #include "aloam_ros_common.hpp"
@@ -8,11 +9,15 @@
 namespace {
 aloam_ctx* g_ctx = nullptr;
 ros::Publisher pubLaserCloud, pubCornerPointsSharp, pubCornerPointsLessSharp, pubSurfPointsFlat, pubSurfPointsLessFlat, pubRemovePoints;
+std::vector<ros::Publisher> pubEachScan;
 std::vector<float> g_repack;
+const bool PUB_EACH_LINE = false;                          // reference src/scanRegistration.cpp:81
+int g_n_scans = 16;
 }  // namespace
 aloam_ctx* aloam_node_context() { return g_ctx; }
 
 void laserCloudHandler(const sensor_msgs::PointCloud2ConstPtr& msg) {
+  const auto t_whole = std::chrono::steady_clock::now();
   const int n = static_cast<int>(msg->width * msg->height);
   const int ox = aloam_host::field_offset(*msg, "x"), oy = aloam_host::field_offset(*msg, "y"), oz = aloam_host::field_offset(*msg, "z");
   const void* scans[1];
@@ -35,6 +40,16 @@ void laserCloudHandler(const sensor_msgs::PointCloud2ConstPtr& msg) {
   pubCornerPointsLessSharp.publish(aloam_host::cloud_msg(g_ctx, ALOAM_CLOUD_LESS_SHARP, stamp, "/camera_init"));
   pubSurfPointsFlat.publish(aloam_host::cloud_msg(g_ctx, ALOAM_CLOUD_FLAT, stamp, "/camera_init"));
   pubSurfPointsLessFlat.publish(aloam_host::cloud_msg(g_ctx, ALOAM_CLOUD_LESS_FLAT, stamp, "/camera_init"));
+  if (PUB_EACH_LINE) {                                     // one topic per ring (:444-454): slices of the ring-ordered cloud
+    std::vector<int> start(g_n_scans), count(g_n_scans);
+    const int nc = aloam_cloud_size(g_ctx, 0, ALOAM_CLOUD_FULL);
+    std::vector<float> full(4 * static_cast<size_t>(nc > 0 ? nc : 1));
+    if (nc > 0 && aloam_get_cloud(g_ctx, 0, ALOAM_CLOUD_FULL, full.data(), nc) == nc && aloam_get_ring_ranges(g_ctx, 0, start.data(), count.data()) == g_n_scans)
+      for (int i = 0; i < g_n_scans; i++) pubEachScan[i].publish(aloam_host::xyzi_to_msg(full.data() + 4 * static_cast<size_t>(start[i]), count[i], stamp, "/camera_init"));
+  }
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_whole).count();
+  printf("scan registration time %f ms *************\n", ms);
+  if (ms > 100) ROS_WARN("scan registration process over 100ms");   // :456-458
 }
 
 int main(int argc, char** argv) {
@@ -55,7 +70,8 @@ int main(int argc, char** argv) {
   cfg.min_range = static_cast<float>(minimum_range);
   cfg.batch = 1;
   cfg.max_points = 400000;                                 // the reference's global arrays (:66-69)
-  if (aloam_create(&cfg, &g_ctx) != ALOAM_OK) {
+  g_n_scans = n_scans;
+  if (aloam_create_stages(&cfg, ALOAM_STAGE_REGISTRATION, &g_ctx) != ALOAM_OK) {   // this node hosts stage 1 only
     ROS_ERROR("aloam_create: %s", g_ctx ? aloam_last_error(g_ctx) : "out of memory");
     return 1;
   }
@@ -66,6 +82,8 @@ int main(int argc, char** argv) {
   pubSurfPointsFlat = nh.advertise<sensor_msgs::PointCloud2>("/laser_cloud_flat", 100);
   pubSurfPointsLessFlat = nh.advertise<sensor_msgs::PointCloud2>("/laser_cloud_less_flat", 100);
   pubRemovePoints = nh.advertise<sensor_msgs::PointCloud2>("/laser_remove_points", 100);   // advertised, never published (:490)
+  if (PUB_EACH_LINE)
+    for (int i = 0; i < n_scans; i++) pubEachScan.push_back(nh.advertise<sensor_msgs::PointCloud2>("/laser_scanid_" + std::to_string(i), 100));   // :492-499
   ros::spin();
   aloam_destroy(g_ctx);
   g_ctx = nullptr;

@@ -33,7 +33,8 @@ enum {
   ALOAM_E_ARG = -1,        /* bad argument */
   ALOAM_E_SCAN_LINES = -2, /* n_scans not 16/32/64 without ring_from_field (reference src/scanRegistration.cpp:472-476) */
   ALOAM_E_EMPTY = -3,      /* no point of some scan survives the NaN / minimum-range filter */
-  ALOAM_E_CAPACITY = -4,   /* a scan exceeds max_points or a ring exceeds max_ring_points */
+  ALOAM_E_CAPACITY = -4,   /* a scan exceeds max_points, a ring exceeds max_ring_points, or (mapping) the map pool / voxel scratch was too small
+                              for the last step: that step has still run, the points that did not fit are missing from the map */
   ALOAM_E_HIP = -5,        /* HIP runtime error / no device */
   ALOAM_E_STATE = -6       /* call order (e.g. odometry before any registration) */
 };
@@ -78,6 +79,11 @@ typedef struct aloam_odom_stats {
 /* ---- lifetime -------------------------------------------------------------------------------------------- */
 void aloam_default_config(aloam_config* cfg);                       /* HDL-64 launch values, batch 1           */
 int aloam_create(const aloam_config* cfg, aloam_ctx** out);          /* replaces the nodes' global state (src/scanRegistration.cpp:60-83, src/laserOdometry.cpp:59-108) */
+/* The reference runs its three stages as three processes; a node that hosts one stage only needs that stage's device buffers.
+ * `stages` = any combination of ALOAM_STAGE_*; entry points of a stage that was left out fail with ALOAM_E_STATE.
+ * aloam_create == aloam_create_stages(cfg, ALOAM_STAGE_ALL, out). */
+enum { ALOAM_STAGE_REGISTRATION = 1, ALOAM_STAGE_ODOMETRY = 2, ALOAM_STAGE_MAPPING = 4, ALOAM_STAGE_ALL = 7 };
+int aloam_create_stages(const aloam_config* cfg, int stages, aloam_ctx** out);
 void aloam_destroy(aloam_ctx* ctx);
 const char* aloam_last_error(const aloam_ctx* ctx);                  /* replaces printf / ROS_BREAK diagnostics */
 void* aloam_stream(aloam_ctx* ctx);                                  /* the hipStream_t all work is queued on   */
@@ -108,6 +114,9 @@ int aloam_process_host(aloam_ctx* ctx, const void* h_scans, long long seq_stride
 /* Replaces the node's globals (cube arrays laserCloudCornerArray / SurfArray[4851], q_wmap_wodom, t_wmap_wodom, `parameters`,
  * laserCloudCen*; src/laserMapping.cpp:72-116) and reads the launch parameters mapping_line_resolution / mapping_plane_resolution
  * (:898-905).  pool_points = capacity of the device-resident map per sequence and feature class.  Call once, before the first step. */
+/* Limits: the map of one sequence and class lives in pool_points points (cubes grow by doubling, the pool is compacted when
+ * fragmented); one cube may hold up to the whole pool.  A frame whose points do not fit is reported by aloam_synchronize as
+ * ALOAM_E_CAPACITY for that step only — the flag is reset by the next aloam_mapping_step. */
 int aloam_mapping_enable(aloam_ctx* ctx, float mapping_line_resolution, float mapping_plane_resolution, int pool_points);
 /* One frame for every sequence, asynchronous.  Consumes what the odometry node publishes for the frame — /laser_cloud_corner_last,
  * /laser_cloud_surf_last, /velodyne_cloud_3, /laser_odom_to_init (src/laserOdometry.cpp:508-591) — straight from the context

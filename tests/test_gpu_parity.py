@@ -373,3 +373,37 @@ def test_host_batch_entry_is_double_buffered_and_matches_device_entry(O, binding
     o1 = O.Oracle(n_scans=64, min_range=model.min_range)
     _assert_features_equal(o1.scan_register(x), g1.features(), "pageable host")
     g1.close(); g_host.close(); g_dev.close()
+
+
+def test_stage_sized_contexts(O, binding, sequence):
+    """aloam_create_stages: a context that hosts one stage (what each ROS node shim creates) gives the same results as the full
+    one through the hand-over the topics allow, and refuses the other stages' entry points with ALOAM_E_STATE."""
+    scans, R, t, model = sequence("VLP-16", 3, seed=6)
+    full = _mk(binding, model, max_points=40000)
+    reg = _mk(binding, model, max_points=40000, stages=binding.STAGE_REGISTRATION)
+    odo = _mk(binding, model, max_points=40000, stages=binding.STAGE_ODOMETRY)
+    mp = _mk(binding, model, max_points=40000, stages=binding.STAGE_MAPPING)
+    fullm = _mk(binding, model, max_points=40000)
+    fullm.mapping_enable(0.2, 0.4, 65536); mp.mapping_enable(0.2, 0.4, 65536)
+    for x in scans:
+        full.scan_register(x); reg.scan_register(x)
+        f = reg.features()
+        _assert_features_equal(full.features(), f, "registration-only context")
+        odo.set_features(f)
+        full.odometry_step(); odo.odometry_step()
+        pf, po = full.pose(), odo.pose()
+        for key in ("q_w", "t_w", "q_lc", "t_lc"):
+            assert np.array_equal(pf[key], po[key]), key
+        corner, surf = odo.cloud(binding.CLOUD_CORNER_LAST), odo.cloud(binding.CLOUD_SURF_LAST)
+        assert bits_equal(corner, full.cloud(binding.CLOUD_CORNER_LAST)) and bits_equal(surf, full.cloud(binding.CLOUD_SURF_LAST))
+        a = mp.mapping_step_inputs(po["q_w"], po["t_w"], corner, surf, f["cloud"])
+        b = fullm.mapping_step_inputs(po["q_w"], po["t_w"], corner, surf, f["cloud"])
+        for key in ("q_w", "t_w"):
+            assert np.array_equal(a[key], b[key]), key
+    for ctx, call in ((reg, lambda c: c.odometry_step()), (odo, lambda c: c.scan_register(scans[0])), (reg, lambda c: c.mapping_enable()),
+                      (mp, lambda c: c.odometry_step()), (mp, lambda c: c.cloud(binding.CLOUD_SHARP))):
+        with pytest.raises(binding.AloamError) as e:
+            call(ctx)
+        assert e.value.code == binding.E_STATE
+    for c in (full, reg, odo, mp, fullm):
+        c.close()
