@@ -302,7 +302,21 @@ __global__ __launch_bounds__(1024) void k_vox_setup(VoxArgs v) {
     ko += n;
     to += nt;
   }
-  if (tid == 0) { v.counters[0] = bad ? 0 : total_tiles; if (bad) atomicOr(&v.counters[1], kMapErrKeys); }
+  // the largest number of merge levels any segment of this call needs: the merge launches behind it return at once
+  __shared__ int s_maxt;
+  if (tid == 0) s_maxt = 0;
+  __syncthreads();
+  int mt = 0;
+  for (int s = s0; s < s1; ++s) mt = max(mt, v.segs[s].ntiles);
+  if (mt > 0) atomicMax(&s_maxt, mt);
+  __syncthreads();
+  if (tid == 0) {
+    int need = 0;
+    while ((1 << need) < s_maxt) ++need;
+    v.counters[2] = need;
+    v.counters[0] = bad ? 0 : total_tiles;
+    if (bad) atomicOr(&v.counters[1], kMapErrKeys);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_vox_bbox(VoxArgs v) {
@@ -380,6 +394,7 @@ __global__ __launch_bounds__(256) void k_vox_keys_sort(VoxArgs v) {
 // run (keys are unique, so no tie rule is needed).  src = keys[level & 1], dst = the other buffer.
 __global__ __launch_bounds__(256) void k_vox_merge(VoxArgs v, int level) {
   const int tid = threadIdx.x;
+  if (level > v.counters[2]) return;                                       // no segment of this call is that large (k_vox_setup)
   for (int gt = blockIdx.x; gt < v.counters[0]; gt += gridDim.x) {   // grid-stride over the tile work list
   const VoxSeg sg = v.segs[v.tile_seg[gt]];
   const int t = gt - sg.tile0;
@@ -906,7 +921,10 @@ __global__ __launch_bounds__(256) void k_map_fit(MapArgs a) {
 // =======================================================================================================
 // solve
 // =======================================================================================================
-constexpr int kMapSolveThreads = 256;    // more waves do not pay: the kernel needs 256 VGPRs per lane for the f64 sums
+#ifndef ALOAM_MAP_SOLVE_THREADS
+#define ALOAM_MAP_SOLVE_THREADS 256
+#endif
+constexpr int kMapSolveThreads = ALOAM_MAP_SOLVE_THREADS;    // more waves do not pay: the kernel needs 256 VGPRs per lane for the f64 sums
 template <bool WITH_JAC>
 __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const double t[3], double* acc, int* n_edge, int* n_norm) {
   const int tid = threadIdx.x;
