@@ -73,7 +73,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="independent sequences per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="independent sequences per GPU (measured: 256 -> 77 k sweeps/s, 512 -> 86 k, 1024 -> 90 k, 2048 -> 93 k)")
     ap.add_argument("--frames", type=int, default=6, help="stored sweeps per sequence (replayed ping-pong)")
     ap.add_argument("--sensor", default="HDL-64", help="headline workload sensor (HDL-64 = BASELINE configs[1]; ROWS128 = configs[3])")
     ap.add_argument("--mapping", action="store_true", help="headline workload = BASELINE configs[2]: scan-to-map refinement after every sweep")

@@ -23,7 +23,7 @@ python - <<PY
 import json
 f = json.load(open("$O/pmc_fetch.json")); w = json.load(open("$O/pmc_write.json"))
 args = "$*".split()
-json.dump({"batch": int(args[args.index("--batch") + 1]) if "--batch" in args else 512, "mapping": "--mapping" in args,
+json.dump({"batch": int(args[args.index("--batch") + 1]) if "--batch" in args else 1024, "mapping": "--mapping" in args,
            "sensor": args[args.index("--sensor") + 1] if "--sensor" in args else "HDL-64",
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of python bench.py --no-cpu-baseline --steps 3 --warmup 1 $* (tools/gpu_pmc.sh $TAG)",
            "fetch_kib": {k: v["FETCH_SIZE"] for k, v in f.items() if "FETCH_SIZE" in v}, "write_kib": {k: v["WRITE_SIZE"] for k, v in w.items() if "WRITE_SIZE" in v},
