@@ -1,8 +1,8 @@
-"""a-loam_amd — MI355X-native A-LOAM hot path (scan registration + scan-to-scan odometry).
+"""a-loam_amd — what the MI355X A-LOAM hot path needs, nothing else.
 
-The directory name follows the project layout contract and is not a Python identifier; import it with
-    aloam = importlib.import_module("a-loam_amd")
-The product is the C-ABI shared library built from csrc/ (include/aloam_mi355x.h); this package only holds
-the ctypes binding used by tests / bench (binding.py), the synthetic input generator (synthetic.py) and the
-KITTI file readers (kitti_io.py).
+csrc/       HIP kernels (gfx950) + the C-ABI host side -> lib/libaloam_mi355x.so (include/aloam_mi355x.h)
+host/       the three ROS node shims that keep the aloam_velodyne topic surface and call the C ABI
+binding.py  ctypes stub of the C ABI (tests, bench.py); no second implementation
+synthetic.py  seeded synthetic sweeps (regular and KITTI-shaped rough ones); shard.py  sequence -> rank assignment
+KITTI-layout input and ground-truth evaluation live in tools/run_kitti.py.
 """
