@@ -524,7 +524,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
 }
 
 template <int NPAD>
-__global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
+__global__ __launch_bounds__(256, NPAD <= 2048 ? 7 : 2) void k_ring_features(RegArgs a, float leaf) {   // 7 waves per SIMD = the 7 workgroups per CU the LDS footprint allows
   constexpr int MAXN = NPAD + 11;
   constexpr int ITEMS = (MAXN + 255) / 256;
   const int r = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // ring-major over the batch, see voxel_runs_tail
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // region A (aliased over time): two 266-point xyz tiles during the curvature pass, then the curvature per point, then the voxel
   // index per element, then the run keys.  Keeping it at 8 * NPAD bytes is what lets seven workgroups share a CU's LDS.
-  constexpr int A_BYTES = 8 * NPAD;
+  constexpr int A_BYTES = 8 * NPAD + 128;                                     // + room for the packed voxel cells behind the curvatures
   constexpr int TW = 256 + 10;                                                // a chunk of 256 points + 5 on either side
   static_assert(2 * 3 * TW * 4 <= A_BYTES && 4 * MAXN <= A_BYTES, "region A holds the curvature tiles and the curvature array");
   float (*tile)[3][TW] = reinterpret_cast<float (*)[3][TW]>(smem);
@@ -556,6 +556,15 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
   short* s_pick = reinterpret_cast<short*>(s_misc + 48);      // s_misc: [0] scratch, [1..6] pick counts, [8..13] spill marks, [16..], [24..], [32..] sector offsets
 
+  // 0.2 m voxel cell of every point, packed 11 + 11 + 10 bits (+-204 m, +-102 m in z), written while the point is in the
+  // curvature tile: the voxel filter of the less-flat points then needs no second and third pass over the ring in global memory
+  // (its bounding box in cells and the voxel indices are integer work on this array).  A point outside that range (s_misc[44])
+  // or a box of more than 2^31 cells sends the ring down the float path, which is pcl::VoxelGrid's arithmetic as written.
+  constexpr int CELLS_OFF = (4 * MAXN + 15) & ~15;
+  static_assert(CELLS_OFF + 4 * MAXN <= A_BYTES, "the packed cells sit behind the curvature array in region A");
+  unsigned* cells = reinterpret_cast<unsigned*>(smem + CELLS_OFF);
+  const float inv = 1.0f / leaf;
+  if (tid == 0) s_misc[44] = 0;
   const float4* cloud = a.cloud + (long long)b * a.cap + start;
   // ---- curvature (:256-266) + gap flags, kept in registers until the tiles are retired.  The ring goes through LDS in chunks
   // of 256 points (thread tid owns point it * 256 + tid = tile column tid + 5); the next chunk is fetched while this one is used.
@@ -594,6 +603,10 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       }
       flags[i] = f;
       label[i] = 0;
+      const float fx = floorf(xs[0] * inv), fy = floorf(ys[0] * inv), fz = floorf(zs[0] * inv);
+      const bool okc = fabsf(fx) < 1024.f && fabsf(fy) < 1024.f && fabsf(fz) < 512.f;
+      if (!okc) s_misc[44] = 1;
+      cells[i] = okc ? (unsigned)((int)fx + 1024) | ((unsigned)((int)fy + 1024) << 11) | ((unsigned)((int)fz + 512) << 22) : 0u;
     }
     if (more) {
       const int nb = (it + 1) & 1;
@@ -682,29 +695,74 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   if (a.store_debug) for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
 
   // ---- pcl::VoxelGrid (leaf 0.2) over the less-flat points of this ring (:401-405)
-  float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-  for (int e = tid; e < L; e += 256) {
-    const int i = e + 5;
-    if (label[i] <= 0) {
-      const float4 p = cloud[i];
-      mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
-      mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
-      mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  // Points follow the ring, so consecutive less-flat points mostly share a voxel: the sort works on RUNS of consecutive
+  // same-voxel members, keyed (voxel index, first element), typically a third of the points.  Runs of one voxel end up adjacent
+  // and in ascending element order, i.e. the members of a voxel are still summed in input order.
+  unsigned* vis = reinterpret_cast<unsigned*>(smem);                          // region A: voxel index per element [NPAD], later the run keys
+  static_assert(8 * NPAD <= A_BYTES, "region A holds the voxel indices, then the run keys");
+  bool overflow = false;
+  long long cells_in_box = 0;                                                // every voxel index is below this
+  bool voxels_done = false;
+  int (*s_redi)[4] = reinterpret_cast<int (*)[4]>(s_red);
+  if (s_misc[44] == 0) {
+    // integer path: min_b = floor(min * inv) = min of floor(p * inv) (floor is monotone), likewise max_b; PCL's own overflow
+    // guard multiplies int((max - min) * inv) + 1 <= div_b + 1 per axis, so a product of (div_b + 1) below 2^31 settles it
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (int e = tid; e < L; e += 256) {
+      const int i = e + 5;
+      if (label[i] <= 0) {
+        const unsigned c = cells[i];
+        const int cx = (int)(c & 2047u), cy = (int)((c >> 11) & 2047u), cz = (int)(c >> 22);
+        mn[0] = min(mn[0], cx); mx[0] = max(mx[0], cx); mn[1] = min(mn[1], cy); mx[1] = max(mx[1], cy); mn[2] = min(mn[2], cz); mx[2] = max(mx[2], cz);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      for (int d = 32; d > 0; d >>= 1) { mn[q] = min(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = max(mx[q], __shfl_down(mx[q], d, 64)); }
+      if (lane == 0) { s_redi[q][wave] = mn[q]; s_redi[3 + q][wave] = mx[q]; }
+    }
+    __syncthreads();
+    int minc[3], divc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      minc[q] = min(min(s_redi[q][0], s_redi[q][1]), min(s_redi[q][2], s_redi[q][3]));
+      divc[q] = max(max(s_redi[3 + q][0], s_redi[3 + q][1]), max(s_redi[3 + q][2], s_redi[3 + q][3])) - minc[q] + 1;
+    }
+    __syncthreads();                                                         // s_red may be needed by the float path below
+    if (divc[0] > 0 && (long long)(divc[0] + 1) * (divc[1] + 1) * (divc[2] + 1) <= 2147483647ll) {
+      cells_in_box = (long long)divc[0] * divc[1] * divc[2];
+      for (int e = tid; e < L; e += 256) {
+        const int i = e + 5;
+        unsigned vi = 0xffffffffu;                                            // not a member (corner-labelled)
+        if (label[i] <= 0) {
+          const unsigned c = cells[i];
+          const int i0 = (int)(c & 2047u) - minc[0], i1 = (int)((c >> 11) & 2047u) - minc[1], i2 = (int)(c >> 22) - minc[2];
+          vi = (unsigned)(i0 + i1 * divc[0] + i2 * divc[0] * divc[1]);
+        }
+        vis[e] = vi;
+      }
+      voxels_done = true;
     }
   }
+  if (!voxels_done) {                                                        // float path: the bounding box and the indices from the points themselves
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int e = tid; e < L; e += 256) {
+      const int i = e + 5;
+      if (label[i] <= 0) {
+        const float4 p = cloud[i];
+        mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+        mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+        mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+      }
+    }
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    for (int d = 32; d > 0; d >>= 1) { mn[q] = fminf(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = fmaxf(mx[q], __shfl_down(mx[q], d, 64)); }
-    if (lane == 0) { s_red[q][wave] = mn[q]; s_red[3 + q][wave] = mx[q]; }
-  }
-  __syncthreads();
-  const float inv = 1.0f / leaf;
-  int minb[3], divb[3];
-  float fminb[3];
-  bool overflow;
-  long long cells;
-  {
-    float gmn[3], gmx[3];
+    for (int q = 0; q < 3; ++q) {
+      for (int d = 32; d > 0; d >>= 1) { mn[q] = fminf(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = fmaxf(mx[q], __shfl_down(mx[q], d, 64)); }
+      if (lane == 0) { s_red[q][wave] = mn[q]; s_red[3 + q][wave] = mx[q]; }
+    }
+    __syncthreads();
+    int minb[3], divb[3];
+    float fminb[3], gmn[3], gmx[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       gmn[q] = fminf(fminf(s_red[q][0], s_red[q][1]), fminf(s_red[q][2], s_red[q][3]));
@@ -718,34 +776,29 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       divb[q] = (int)floorf(gmx[q] * inv) - minb[q] + 1;
       fminb[q] = (float)minb[q];
     }
-    cells = (long long)divb[0] * divb[1] * divb[2];                          // every voxel index is below this
-  }
-  // Points follow the ring, so consecutive less-flat points mostly share a voxel: the sort works on RUNS of consecutive
-  // same-voxel members, keyed (voxel index, first element), typically a third of the points.  Runs of one voxel end up adjacent
-  // and in ascending element order, i.e. the members of a voxel are still summed in input order.
-  unsigned* vis = reinterpret_cast<unsigned*>(smem);                          // region A: voxel index per element [NPAD], later the run keys
-  static_assert(8 * NPAD <= A_BYTES, "region A holds the voxel indices, then the run keys");
-  for (int e = tid; e < L; e += 256) {
-    const int i = e + 5;
-    unsigned vi = 0xffffffffu;                                                // not a member (corner-labelled)
-    if (label[i] <= 0) {
-      if (overflow) vi = (unsigned)e;         // every point its own cell -> output = input, in order
-      else {
-        const float4 p = cloud[i];
-        const int i0 = (int)(floorf(p.x * inv) - fminb[0]);
-        const int i1 = (int)(floorf(p.y * inv) - fminb[1]);
-        const int i2 = (int)(floorf(p.z * inv) - fminb[2]);
-        vi = (unsigned)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]);
+    cells_in_box = (long long)divb[0] * divb[1] * divb[2];
+    for (int e = tid; e < L; e += 256) {
+      const int i = e + 5;
+      unsigned vi = 0xffffffffu;                                              // not a member (corner-labelled)
+      if (label[i] <= 0) {
+        if (overflow) vi = (unsigned)e;         // every point its own cell -> output = input, in order
+        else {
+          const float4 p = cloud[i];
+          const int i0 = (int)(floorf(p.x * inv) - fminb[0]);
+          const int i1 = (int)(floorf(p.y * inv) - fminb[1]);
+          const int i2 = (int)(floorf(p.z * inv) - fminb[2]);
+          vi = (unsigned)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]);
+        }
       }
+      vis[e] = vi;
     }
-    vis[e] = vi;
   }
   __syncthreads();
   // 32-bit run keys (voxel index << EB | first element) whenever the voxel box is small enough — most rings: half the LDS
   // traffic and a third fewer VALU instructions in the sort; the 64-bit keys remain for rings whose box has more cells.
   constexpr int EB = NPAD <= 2048 ? 11 : 12;                                  // bits of an element index
   float4* out = a.less_flat + (long long)b * a.cap;                          // final place: offset = less-flat points of the rings in front
-  if (!ALOAM_RF_KEYS64 && (overflow || cells <= (1ll << (32 - EB))))
+  if (!ALOAM_RF_KEYS64 && (overflow || cells_in_box <= (1ll << (32 - EB))))
     voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch);
   else
     voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch);
@@ -781,7 +834,7 @@ __global__ __launch_bounds__(64) void k_cloud_sizes(RegArgs a) {
 // -------------------------------------------------------------------------------------------------------
 size_t ring_features_lds_bytes(int npad) {
   const int maxn = npad + 11;
-  const int a_bytes = 8 * npad;
+  const int a_bytes = 8 * npad + 128;
   const int flag_bytes = (maxn + 15) & ~15;
   return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 48) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
 }
