@@ -439,20 +439,18 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
     if (lane == 0) s_scan[it * 4 + wave] = __popcll(m);
   }
   __syncthreads();
-  int n_runs = 0;
-  {
-    int run = 0;
-#pragma unroll
-    for (int it = 0; it < EIT; ++it) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int c = s_scan[it * 4 + w];
-        if (w == wave) hrank[it] += run;
-        run += c;
-      }
-    }
-    n_runs = run;
+  // exclusive prefix of the 4 x EIT (round, wave) counts by one wave (DPP scan), instead of every thread summing the whole table
+  static_assert(4 * EIT <= 64, "one wave scans the table");
+  if (wave == 0) {
+    const int c = lane < 4 * EIT ? s_scan[lane] : 0;
+    const int inc = wave_scan_i32<false>(c);
+    if (lane < 4 * EIT) s_scan[lane] = inc - c;
+    if (lane == 63) s_scan[64] = inc;
   }
+  __syncthreads();
+  const int n_runs = s_scan[64];
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) hrank[it] += s_scan[it * 4 + wave];
 #pragma unroll
   for (int it = 0; it < EIT; ++it)
     if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = (K)(((K)myvi[it] << SHIFT) | (K)e); }   // vis is dead: every thread read its share before the barrier
@@ -474,20 +472,16 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
     if (lane == 0) s_scan[it * 4 + wave] = __popcll(m);
   }
   __syncthreads();
-  {
-    int run = 0;
-#pragma unroll
-    for (int it = 0; it < EIT; ++it) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int c = s_scan[it * 4 + w];
-        if (w == wave) vrank[it] += run;
-        run += c;
-      }
-    }
-    if (tid == 0) publish_count(lb_lf + ring, epoch, run);                   // number of occupied voxels = less-flat points of this ring
-    n_vox = run;
+  if (wave == 0) {
+    const int c = lane < 4 * EIT ? s_scan[lane] : 0;
+    const int inc = wave_scan_i32<false>(c);
+    if (lane < 4 * EIT) s_scan[lane] = inc - c;
+    if (lane == 63) { s_scan[64] = inc; publish_count(lb_lf + ring, epoch, inc); }   // number of occupied voxels = less-flat points of this ring
   }
+  __syncthreads();
+  n_vox = s_scan[64];
+#pragma unroll
+  for (int it = 0; it < EIT; ++it) vrank[it] += s_scan[it * 4 + wave];
   // offsets of this ring in the four clouds = what the rings in front produced.  The launch orders the workgroups ring-major
   // over the sweeps of the batch (blockIdx.x = sweep), so the rings in front of this one were dispatched a whole batch row
   // earlier and have normally published long ago: the gather does not wait.
@@ -524,7 +518,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
 }
 
 template <int NPAD>
-__global__ __launch_bounds__(256, NPAD <= 2048 ? 7 : 2) void k_ring_features(RegArgs a, float leaf) {   // 7 waves per SIMD = the 7 workgroups per CU the LDS footprint allows
+__global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int MAXN = NPAD + 11;
   constexpr int ITEMS = (MAXN + 255) / 256;
   const int r = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // ring-major over the batch, see voxel_runs_tail
