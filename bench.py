@@ -46,6 +46,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
+STAGE_KERNELS = {"map_associate": ["k_map_search<0>", "k_map_search<1>", "k_map_fit<0>", "k_map_fit<1>"],   # a profiled stage = these kernels, once each
+                 "map_solve": ["k_map_solve"], "map_register": ["k_map_register"], "map_begin": ["k_map_begin"],
+                 "map_grid": ["k_mapgrid_count", "k_mapgrid_scan", "k_mapgrid_fill"]}
 RK_NAMES = {"k_associate[plane]": "k_associate<true, false>", "k_associate[corner]": "k_associate<false, false>",
             "k_ring_features": "k_ring_features<2048>", "k_solve": "k_solve<false>"}
 
@@ -84,6 +87,7 @@ def parse_args():
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip host-input rate, configs[2]/[3] sub-workloads and latency")
     ap.add_argument("--host-input", action="store_true", help="(kept for compatibility: the host-fed rate is part of the default line)")
     ap.add_argument("--latency-sweeps", type=int, default=120)
+    ap.add_argument("--rough", action="store_true", help="KITTI-shaped irregular sweeps (random no-returns, ragged rings, noisy sectors, repeated returns) instead of the clean synthetic ones")
     return ap.parse_args()
 
 
@@ -120,8 +124,8 @@ def self_spawn(args):
 class Workload:
     """Synthetic sweeps of B sequences x T frames, resident in HBM, and the bookkeeping to replay them."""
 
-    def __init__(self, syn, torch, sensor, B, T, rank, dev):
-        self.sensor, self.B, self.T = sensor, B, T
+    def __init__(self, syn, torch, sensor, B, T, rank, dev, rough=False):
+        self.sensor, self.B, self.T, self.rough = sensor, B, T, rough
         self.model = syn.sensor_model(sensor, device=dev)
         self.NP = self.model.dirs.shape[0]
         t0 = time.time()
@@ -134,7 +138,7 @@ class Workload:
             R, tt = syn.trajectory(T, step=1.0, seed=gseq, start_angle=0.37 * gseq)
             gen = torch.Generator(device=dev).manual_seed(9000 + gseq)
             for k in range(T):
-                s = syn.render_scan(worlds[gseq % len(worlds)], self.model, R[k], tt[k], 0.02, gen)
+                s = syn.render_scan(worlds[gseq % len(worlds)], self.model, R[k], tt[k], 0.02, gen, rough=rough)
                 self.counts[b, k] = s.shape[0]
                 self.data[b, k, : s.shape[0]] = s
             if b < 4:
@@ -154,7 +158,7 @@ class Workload:
 
     def describe(self, mapping):
         m = self.model
-        return f"synthetic {self.sensor} {m.n_scans}x{m.columns} ({self.NP} pts/sweep), " + (
+        return f"synthetic {self.sensor} {m.n_scans}x{m.columns} ({self.NP} pts/sweep{', rough: dropouts / ragged rings / repeated returns' if self.rough else ''}), " + (
             "odometry + laserMapping scan-to-map refinement every sweep" if mapping else "odometry only (scan registration + scan-to-scan odometry, no laserMapping)")
 
 
@@ -227,9 +231,9 @@ def roofline_of(prof, steps, B, sensor, mapping):
         except (OSError, ValueError):
             continue
         if pm.get("batch") == B and pm.get("mapping") == bool(mapping) and pm.get("sensor") == sensor:
-            cands = [k for k in pm.get("fetch_kib", {}) if k == RK_NAMES.get(dname, dname) or k.split("<")[0] == dname]
-            if cands and cands[0] in pm.get("write_kib", {}):
-                r["traffic"] = round((2.0 * pm["fetch_kib"][cands[0]] + pm["write_kib"][cands[0]]) * 1024.0)
+            cands = STAGE_KERNELS.get(dname) or [k for k in pm.get("fetch_kib", {}) if k == RK_NAMES.get(dname, dname) or k.split("<")[0] == dname][:1]
+            if cands and all(k in pm.get("fetch_kib", {}) and k in pm.get("write_kib", {}) for k in cands):
+                r["traffic"] = round(sum(2.0 * pm["fetch_kib"][k] + pm["write_kib"][k] for k in cands) * 1024.0)
                 r["traffic_source"] = pm.get("source", "profiles/")
             break
     return r
@@ -388,7 +392,7 @@ def main():
         binding.build()
 
     B, T = args.batch, args.frames
-    wl = Workload(syn, torch, args.sensor, B, T, rank, dev)
+    wl = Workload(syn, torch, args.sensor, B, T, rank, dev, rough=args.rough)
     NC = max(1, args.contexts)
     assert B % NC == 0, "--batch must be a multiple of --contexts"
     ctxs = [wl.ctx(binding, B // NC, local_rank) for _ in range(NC)]
