@@ -10,9 +10,11 @@
 //   k_ring_features   :256-407   one workgroup per (sweep, ring): 11-tap curvature from alternating 266-point LDS
 //                                tiles; std::sort + greedy corner / flat picking with neighbour suppression evaluated as
 //                                an iterative arg-max per sector (no sort); less-flat gather + 0.2 m voxel centroids
-//                                (pcl::VoxelGrid stand-in: runs of same-voxel points sorted by an LDS bitonic)
-//                              ; the ring workgroups publish their counts to each other, so every pick and every less-flat
-//                                centroid is written once, at its final place in the reference's output order (:304-310,356,407)
+//                                (pcl::VoxelGrid stand-in: voxel cells packed into LDS during the curvature pass, runs of
+//                                same-voxel points sorted by an LDS bitonic); the ring workgroups publish their counts to
+//                                each other, so every pick and every less-flat centroid is written once, at its final place
+//                                in the reference's output order (:304-310,356,407)
+//   k_cloud_sizes                sizes of the four feature clouds = sums of the published ring counts
 //
 // All of it is HBM/latency-bound integer + f32 work: coalesced 16-B loads, LDS staging, wave64 ballots; no MFMA.
 #include "aloam_device.hpp"
