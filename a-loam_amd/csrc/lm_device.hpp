@@ -185,12 +185,14 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
       for (int c = 0; c < 6; ++c) delta[c] = step[c] * scale[c];
       quat_plus(q, delta, qc);
       for (int k = 0; k < 3; ++k) tc[k] = t[k] + delta[3 + k];
+      // Ceres evaluates the cost at the candidate and, if the step is accepted, residuals + Jacobian there once more.  Here one
+      // pass at the candidate yields both: the cost is the same sum of the same terms, an accepted step needs no second pass over
+      // the correspondence records, and only a rejected step (rare) has computed a Jacobian for nothing.
       double cacc[28];
       for (int k = 0; k < 28; ++k) cacc[k] = 0.0;
-      eval(false, qc, tc, cacc, &ne, &np);
-      double cc[1] = {cacc[27]};
-      block_sum<1, NW>(cc, s_red);
-      const double cost_c = cc[0];
+      eval(true, qc, tc, cacc, &ne, &np);
+      block_sum<28, NW>(cacc, s_red);
+      const double cost_c = cacc[27];
       double sn = 0.0;
       for (int k = 0; k < 4; ++k) sn += (q[k] - qc[k]) * (q[k] - qc[k]);
       for (int k = 0; k < 3; ++k) sn += (t[k] - tc[k]) * (t[k] - tc[k]);
@@ -202,9 +204,7 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
         for (int k = 0; k < 4; ++k) q[k] = qc[k];
         for (int k = 0; k < 3; ++k) t[k] = tc[k];
         x_norm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
-        for (int k = 0; k < 28; ++k) acc[k] = 0.0;
-        eval(true, q, t, acc, &ne, &np);
-        block_sum<28, NW>(acc, s_red);
+        for (int k = 0; k < 28; ++k) acc[k] = cacc[k];
         cost = acc[27];
         unpack(acc);
         gmax = gradient_max();
