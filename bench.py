@@ -359,6 +359,35 @@ def accuracy(binding, wl, local_rank, mapping=False):
             "tolerance": "1e-4 m / 1e-4 rad (BASELINE.json north_star)"}
 
 
+def accuracy_mapping(binding, wl, local_rank, map_pool):
+    """configs[2]: refined (scan-to-map) poses of one sequence over the stored sweeps, GPU vs oracle, and both vs the ground truth."""
+    import oracle_py
+    m = wl.model
+    gpu = wl.ctx(binding, 1, local_rank)
+    gpu.mapping_enable(0.4, 0.8, map_pool)
+    orc = oracle_py.Oracle(n_scans=m.n_scans, min_range=m.min_range, ring_from_field=m.ring_from_field)
+    orc.map_config(0.4, 0.8)
+    host = wl.data[0].cpu().numpy()
+    Rg, tg = wl.gt[0]
+    base = wl.data.data_ptr()
+    max_dt = max_drot = ate_g = ate_o = 0.0
+    for k in range(wl.T):
+        gpu.process_device(base + k * wl.NP * 16, wl.seq_stride, [int(wl.counts[0, k])])
+        gpu.mapping_step()
+        gpu.synchronize()
+        pg = gpu.map_pose(0)
+        orc.scan_register(host[k, : wl.counts[0, k]])
+        po = orc.odometry_step()
+        pm = orc.mapping_step(po["q_w"], po["t_w"], orc.cloud(oracle_py.CLOUD_CORNER_LAST), orc.cloud(oracle_py.CLOUD_SURF_LAST), orc.cloud(oracle_py.CLOUD_FULL))
+        max_dt = max(max_dt, float(np.linalg.norm(pm["t_w"] - pg["t_w"])))
+        max_drot = max(max_drot, quat_angle(pm["q_w"], pg["q_w"]))
+        t_gt = Rg[0].T @ (tg[k] - tg[0])
+        ate_g += float(np.sum((pg["t_w"] - t_gt) ** 2)); ate_o += float(np.sum((pm["t_w"] - t_gt) ** 2))
+    gpu.close()
+    return {"gpu_vs_oracle_max_dt_m": max_dt, "gpu_vs_oracle_max_drot_rad": max_drot, "sweeps_compared": wl.T,
+            "ate_gpu_vs_gt_m": (ate_g / wl.T) ** 0.5, "ate_oracle_vs_gt_m": (ate_o / wl.T) ** 0.5, "tolerance": "1e-4 m / 1e-4 rad (BASELINE.json north_star)"}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def main():
     args = parse_args()
@@ -429,11 +458,14 @@ def main():
         info = cx.map_info(0)
         cx.close()
         lat_map = latency(binding, wl, local_rank, max(30, args.latency_sweeps // 3), mapping=True)
+        acc_map = accuracy_mapping(binding, wl, local_rank, args.map_pool) if not args.no_cpu_baseline else None
         out["workloads"] = {"configs[2] odometry + laserMapping": {
             "workload": wl.describe(True), "value": round(B * steps2 / el2, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el2 / steps2, 4),
             "steps": steps2, "warmup": warm2, "sequences_per_gpu": B, "map_pool_points": args.map_pool,
             "roofline": roofline_of(prof2, steps2, B, "HDL-64", True), "map_state_seq0": {k: info[k] for k in ("frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack")},
             "latency": lat_map}}
+        if acc_map is not None:
+            out["workloads"]["configs[2] odometry + laserMapping"]["accuracy"] = acc_map
         del wl
         torch.cuda.empty_cache()
         # ---- BASELINE.json configs[3]: 128 rings x 2048 columns stress (ring index from the 4th float)
