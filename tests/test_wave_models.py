@@ -148,3 +148,79 @@ def test_voxel_centroids_from_sorted_runs_equal_the_plain_definition():
             got.append((s / np.float32(c)).astype(np.float32))
             p = q
         assert len(got) == len(want) and all(np.array_equal(a.view(np.uint32), b.view(np.uint32)) for a, b in zip(got, want)), trial
+
+
+# ------------------------------------------------------------------------------------------------ DPP ladder reductions (round 2)
+def dpp_row_shr(v, n, old):
+    """v_mov_dpp row_shr:n with bound_ctrl off: lane i of every row of 16 takes lane i - n of the same row, `old` where there is none."""
+    out = np.array(old, copy=True)
+    for lane in range(64):
+        src = lane - n
+        if src // 16 == lane // 16 and src >= 0:
+            out[lane] = v[src]
+    return out
+
+
+def dpp_row_bcast(v, which, row_mask, old):
+    """row_bcast:15 (lane 15 of each row -> every lane of the next row) / row_bcast:31 (lane 31 -> rows 2 and 3), written only to the
+    rows in row_mask; other lanes keep `old`."""
+    out = np.array(old, copy=True)
+    for lane in range(64):
+        row = lane // 16
+        if not (row_mask >> row) & 1:
+            continue
+        if which == 15 and row >= 1:
+            out[lane] = v[16 * row - 1]
+        elif which == 31 and row >= 2:
+            out[lane] = v[31]
+    return out
+
+
+def wave_reduce_model(v, is_max):
+    """wave_reduce_u32 (aloam_device.hpp): op(v, dpp(identity, v, ...)) for row_shr 1, 2, 4, 8, row_bcast15 (rows 1, 3), row_bcast31
+    (rows 2, 3); the result is read from lane 63."""
+    ident = 0 if is_max else 0xffffffff
+    op = np.maximum if is_max else np.minimum
+    v = np.asarray(v, np.uint64).copy()
+    idv = np.full(64, ident, np.uint64)
+    for n in (1, 2, 4, 8):
+        v = op(v, dpp_row_shr(v, n, idv))
+    v = op(v, dpp_row_bcast(v, 15, 0xA, idv))
+    v = op(v, dpp_row_bcast(v, 31, 0xC, idv))
+    return int(v[63])
+
+
+def test_dpp_ladder_reduces_the_whole_wave_into_lane_63():
+    rng = np.random.default_rng(17)
+    for trial in range(500):
+        v = rng.integers(0, 2 ** 32, 64, dtype=np.uint64)
+        if trial % 5 == 0: v[:] = rng.integers(0, 3, 64)                     # many ties
+        if trial % 7 == 0: v[rng.integers(0, 64)] = 0xffffffff
+        assert wave_reduce_model(v, True) == int(v.max()) and wave_reduce_model(v, False) == int(v.min())
+    for lane in range(64):                                                   # a single extreme in every possible lane
+        v = np.full(64, 5, np.uint64); v[lane] = 9
+        assert wave_reduce_model(v, True) == 9
+        v[lane] = 1
+        assert wave_reduce_model(v, False) == 1
+
+
+def wave_min_packed_model(v):
+    """wave_min_packed (aloam_device.hpp): reduce the high words; the low word by v_readlane when one lane holds the minimum, by a
+    second ladder over the tied lanes otherwise."""
+    hi = [int(x) >> 32 for x in v]; lo = [int(x) & 0xffffffff for x in v]
+    mh = wave_reduce_model(hi, False)
+    tied = [l for l in range(64) if hi[l] == mh]
+    ml = lo[tied[0]] if len(tied) == 1 else wave_reduce_model([lo[l] if hi[l] == mh else 0xffffffff for l in range(64)], False)
+    return (mh << 32) | ml
+
+
+def test_packed_minimum_equals_the_64_bit_minimum():
+    rng = np.random.default_rng(23)
+    for trial in range(500):
+        hi = rng.integers(0, 2 ** 32, 64, dtype=np.uint64)
+        lo = rng.integers(0, 2 ** 32, 64, dtype=np.uint64)
+        if trial % 3 == 0: hi[:] = rng.integers(0, 4, 64)                    # exactly equal distances: the tie-break decides
+        v = [(int(h) << 32) | int(l) for h, l in zip(hi, lo)]
+        if trial % 11 == 0: v = [0xffffffffffffffff] * 64                    # nobody holds a candidate
+        if trial % 13 == 0: v[rng.integers(0, 64)] = 0xffffffffffffffff
+        assert wave_min_packed_model(v) == min(v)
