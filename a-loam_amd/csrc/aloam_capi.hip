@@ -67,6 +67,7 @@ struct aloam_ctx {
   float4 *d_sel_sharp = nullptr, *d_sel_flat = nullptr;
   // scan-to-map refinement (allocated by aloam_mapping_enable)
   bool map_on = false;
+  long long map_err_reported = 0;    // capacity events (MapSeq.err_steps, vox counters[3]) aloam_synchronize has already returned
   float map_line_res = 0.4f, map_plane_res = 0.8f;
   int map_pool = 0, map_H[2] = {0, 0}, map_levels = 0, map_cube_levels = 0, map_tile_cap = 0, map_tile_bound[2] = {0, 0}, map_nsegs_max = 0;
   long long map_key_cap = 0;
@@ -199,7 +200,8 @@ int fetch_meta(aloam_ctx* c, int seq, SeqMeta* m) {
 // the throughput entries (aloam_process_device / aloam_process_host) leave those 5 bytes per point out.
 int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, const int* n_in, int stride_bytes, int slot = -1, bool debug_arrays = true) {
   if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
-  if (stride_bytes < 16 || (stride_bytes & 3)) { c->err = "stride_bytes must be >= 16 and a multiple of 4"; return ALOAM_E_ARG; }
+  if (stride_bytes < 12 || (stride_bytes & 3)) { c->err = "stride_bytes must be 12 (x, y, z only) or >= 16, and a multiple of 4"; return ALOAM_E_ARG; }
+  if (stride_bytes == 12 && c->cfg.ring_from_field) { c->err = "ring_from_field needs the 4th float of every record: stride_bytes >= 16"; return ALOAM_E_ARG; }
   for (int b = 0; b < c->B; ++b) {
     if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
     if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
@@ -372,16 +374,32 @@ int aloam_synchronize(aloam_ctx* c) {
   for (int b = 0; b < c->B; ++b) {
     if (m[b].err & kErrEmpty) { c->err = "sequence " + std::to_string(b) + ": no point survives the NaN / minimum-range filter"; return ALOAM_E_EMPTY; }
     if (m[b].err & (kErrRingCap | kErrPointCap)) { c->err = "sequence " + std::to_string(b) + ": a ring exceeds max_ring_points or the scan exceeds max_points"; return ALOAM_E_CAPACITY; }
+    if (m[b].err & kErrInternal) { c->err = "sequence " + std::to_string(b) + ": internal error, a ring workgroup of k_ring_features never published its counts (look-back wait timed out)"; return ALOAM_E_HIP; }
   }
   if (c->map_on) {
     std::vector<MapSeq> ms(c->B);
-    int vc[2] = {0, 0};
+    int vc[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipMemcpy(ms.data(), c->d_mapseq, sizeof(MapSeq) * c->B, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(vc, c->d_vox_counters, sizeof(vc), hipMemcpyDeviceToHost));
-    // both flags describe the LAST mapping step only (reset at its start); the step itself has run: poses and map are valid, the
-    // frame's points that did not fit were left out of the map
-    if (vc[1]) { c->err = "mapping: voxel-filter scratch too small for this frame (raise pool_points)"; return ALOAM_E_CAPACITY; }
-    for (int b = 0; b < c->B; ++b) if (ms[b].err & kMapErrPool) { c->err = "sequence " + std::to_string(b) + ": map pool exhausted in the last step, some points were not inserted (raise pool_points)"; return ALOAM_E_CAPACITY; }
+    // The per-step flags (MapSeq.err, counters[1]) are folded into running counts when the next step starts (k_map_begin), so a
+    // caller that queues many steps and synchronises once still hears about every step that dropped points: reported once, at the
+    // first aloam_synchronize after it happened.  The steps themselves have run: poses and map are valid, the points that did not
+    // fit were left out of the map.
+    long long total = vc[3] + (vc[1] ? 1 : 0);
+    int first_seq = -1;
+    for (int b = 0; b < c->B; ++b) {
+      const int n = ms[b].err_steps + ((ms[b].err & kMapErrPool) ? 1 : 0);
+      if (n > 0 && first_seq < 0) first_seq = b;
+      total += n;
+    }
+    if (total > c->map_err_reported) {
+      const long long fresh = total - c->map_err_reported;
+      c->map_err_reported = total;
+      c->err = "mapping: " + std::to_string(fresh) + " (sequence, step) pair(s) since the last aloam_synchronize ran out of " +
+               (first_seq >= 0 ? "map pool (first: sequence " + std::to_string(first_seq) + ")" : std::string("voxel-filter scratch")) +
+               "; the points that did not fit were not inserted (raise pool_points)";
+      return ALOAM_E_CAPACITY;
+    }
   }
   return ALOAM_OK;
 }
@@ -411,7 +429,7 @@ int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in,
   DeviceScope device_scope(c);
   if (!c || !scans || !n_in) return ALOAM_E_ARG;
   if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
-  if (stride_bytes < 16) { c->err = "stride_bytes must be >= 16"; return ALOAM_E_ARG; }
+  if (stride_bytes < 12 || (stride_bytes & 3)) { c->err = "stride_bytes must be 12 (x, y, z only) or >= 16, and a multiple of 4"; return ALOAM_E_ARG; }
   const size_t seq_stride = (size_t)c->cap * stride_bytes;
   for (int b = 0; b < c->B; ++b) if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
   int slot = 0;
@@ -432,7 +450,7 @@ int aloam_scan_register(aloam_ctx* c, const void* const* scans, const int* n_in,
 static int stage_and_register(aloam_ctx* c, const void* h_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes, bool debug_arrays) {
   if (!c || !h_scans || !n_in) return ALOAM_E_ARG;
   if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
-  if (stride_bytes < 16 || (stride_bytes & 3) || seq_stride_bytes < 0) { c->err = "bad stride"; return ALOAM_E_ARG; }
+  if (stride_bytes < 12 || (stride_bytes & 3) || seq_stride_bytes < 0) { c->err = "bad stride"; return ALOAM_E_ARG; }
   int nmax = 0;
   for (int b = 0; b < c->B; ++b) {
     if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
@@ -446,11 +464,11 @@ static int stage_and_register(aloam_ctx* c, const void* h_scans, long long seq_s
   const size_t row = (size_t)nmax * stride_bytes;
   if (c->B > 1 && (size_t)seq_stride_bytes < row) { c->err = "seq_stride_bytes smaller than a scan"; return ALOAM_E_ARG; }
   if (row > 0) {
-    if (c->B == 1) {
-      HIP_TRY(c, hipMemcpyAsync(c->d_in[slot], h_scans, row, hipMemcpyHostToDevice, c->copy_stream));
-    } else {
-      HIP_TRY(c, hipMemcpy2DAsync(c->d_in[slot], d_seq_stride, h_scans, (size_t)seq_stride_bytes, row, (size_t)c->B, hipMemcpyHostToDevice, c->copy_stream));
-    }
+    // rows 0 .. B-2 as one strided copy of the batch-wide maximum (every row but the last is followed by the next one, so the
+    // extra bytes are readable); the last row with its own length, so that a buffer that ends with the last sweep is never over-read
+    if (c->B > 1) HIP_TRY(c, hipMemcpy2DAsync(c->d_in[slot], d_seq_stride, h_scans, (size_t)seq_stride_bytes, row, (size_t)c->B - 1, hipMemcpyHostToDevice, c->copy_stream));
+    const size_t last = (size_t)n_in[c->B - 1] * stride_bytes;
+    if (last > 0) HIP_TRY(c, hipMemcpyAsync(c->d_in[slot] + (size_t)(c->B - 1) * d_seq_stride, (const char*)h_scans + (size_t)(c->B - 1) * (size_t)seq_stride_bytes, last, hipMemcpyHostToDevice, c->copy_stream));
   }
   HIP_TRY(c, hipEventRecord(c->in_copied[slot], c->copy_stream));
   HIP_TRY(c, hipStreamWaitEvent(c->stream, c->in_copied[slot], 0));
@@ -485,14 +503,13 @@ int aloam_odometry_step(aloam_ctx* c) {
     c->system_inited = true;                       // first frame: no solve (src/laserOdometry.cpp:267-271)
   } else {
     OdomArgs a = odom_args(c);
-    const int max_sharp = c->R * 12, max_flat = c->R * 24;
     { ProfScope p(c, K_BUILD_GRIDS); launch_build_grids(a, c->stream); }          // kd-tree stand-in over the last clouds
     for (int outer = 0; outer < c->cfg.outer_iterations; ++outer) {
       a.outer = outer;
       a.last_outer = outer == c->cfg.outer_iterations - 1;
       { ProfScope p(c, K_TRANSFORM); launch_transform_queries(a, c->stream); }    // TransformToStart of the features (:300, :388)
-      { ProfScope p(c, K_ASSOC_CORNER); launch_associate(a, false, max_sharp, c->stream); }
-      { ProfScope p(c, K_ASSOC_PLANE); launch_associate(a, true, max_flat, c->stream); }
+      { ProfScope p(c, K_ASSOC_CORNER); launch_associate(a, false, c->stream); }
+      { ProfScope p(c, K_ASSOC_PLANE); launch_associate(a, true, c->stream); }
       { ProfScope p(c, K_SOLVE); launch_solve(a, c->stream); }
     }
   }
@@ -646,6 +663,7 @@ int aloam_get_ring_ranges(aloam_ctx* c, int seq, int* start, int* count) {
   DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
+  if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
   if ((rc = sync_and_check(c))) return rc;
   std::vector<int> rs(c->R + 1);
   HIP_TRY(c, hipMemcpy(rs.data(), c->d_ringstart + (size_t)seq * (c->R + 1), sizeof(int) * (c->R + 1), hipMemcpyDeviceToHost));
@@ -657,6 +675,7 @@ int aloam_get_curvature(aloam_ctx* c, int seq, float* out, int cap) {
   DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
+  if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
   if (!c->debug_arrays) { c->err = "curvature is only kept by aloam_scan_register*; the throughput entries (aloam_process_*) skip it"; return ALOAM_E_STATE; }
   SeqMeta m;
   if ((rc = fetch_meta(c, seq, &m))) return rc;
@@ -669,6 +688,7 @@ int aloam_get_labels(aloam_ctx* c, int seq, int* out, int cap) {
   DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
+  if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
   if (!c->debug_arrays) { c->err = "labels are only kept by aloam_scan_register*; the throughput entries (aloam_process_*) skip them"; return ALOAM_E_STATE; }
   SeqMeta m;
   if ((rc = fetch_meta(c, seq, &m))) return rc;
@@ -799,6 +819,7 @@ static MapArgs map_args(aloam_ctx* c) {
   a.addcnt = c->d_addcnt; a.cursor = c->d_cursor; a.compact_flag = c->d_compact_flag;
   a.edges = c->d_medges; a.norms = c->d_mnorms; a.knn = c->d_knn;
   a.lm_max_iterations = c->cfg.lm_max_iterations;
+  a.vox_counters = c->d_vox_counters;
   return a;
 }
 static VoxArgs vox_args(aloam_ctx* c, int n_segs, int levels) {
@@ -876,7 +897,6 @@ int aloam_mapping_step(aloam_ctx* c) {
   if (!c) return ALOAM_E_ARG;
   if (!c->map_on) { c->err = "aloam_mapping_step before aloam_mapping_enable"; return ALOAM_E_STATE; }
   const MapArgs a = map_args(c);
-  HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 1, 0, sizeof(int), c->stream));   // capacity flags are per step (k_map_begin clears the per-sequence one)
   { ProfScope p(c, K_MAP_BEGIN); launch_map_begin(a, c->stream); }
   { ProfScope p(c, K_MAP_VOXEL_STACK);                                      // downSizeFilterCorner / Surf on the incoming clouds (:542-550)
     const VoxArgs v = vox_args(c, c->B * 2, c->map_levels);

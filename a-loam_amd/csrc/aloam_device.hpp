@@ -18,7 +18,7 @@ constexpr int kLessSharpPerSector = 20;// :307
 constexpr int kFlatPerSector = 4;      // :359
 constexpr int kNnTile = 1024;          // targets staged in LDS per NN workgroup
 
-enum ErrBits { kErrEmpty = 1, kErrRingCap = 2, kErrPointCap = 4 };
+enum ErrBits { kErrEmpty = 1, kErrRingCap = 2, kErrPointCap = 4, kErrInternal = 8 };   // kErrInternal: a look-back wait of k_ring_features timed out
 
 struct alignas(16) SeqMeta {           // one per sequence, device resident
   int n_in;
@@ -122,6 +122,7 @@ __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int whic
 __device__ __forceinline__ float4 load_point(const char* base, long long i, int stride) {
   const float* p = reinterpret_cast<const float*>(base + i * (long long)stride);
   if ((stride & 15) == 0) return *reinterpret_cast<const float4*>(p);
+  if (stride == 12) return make_float4(p[0], p[1], p[2], 0.f);                // x, y, z only: the reference never reads the 4th input float
   return make_float4(p[0], p[1], p[2], p[3]);
 }
 

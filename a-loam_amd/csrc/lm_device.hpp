@@ -136,6 +136,8 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
 
   if (n_edges + n_planes == 0) {
     termination = 4;
+  } else if (!isfinite(cost)) {
+    termination = 5;              // Ceres: "Residual and Jacobian evaluation failed" (non-finite residual), parameters untouched
   } else {
     double H[6][6], g[6], scale[6];
     auto unpack = [&](const double* s) {
@@ -145,7 +147,16 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
     };
     unpack(acc);
     for (int c = 0; c < 6; ++c) scale[c] = 1.0 / (1.0 + sqrt(H[c][c]));           // Jacobi scaling, first Jacobian only
-    auto gradient_max = [&]() { double mx = 0.0; for (int c = 0; c < 6; ++c) mx = fmax(mx, fabs(g[c])); return mx; };
+    // Ceres 1.12: gradient_max_norm = |x - Plus(x, -g)|_inf with the unscaled tangent-space gradient g (called before apply_scale)
+    auto gradient_max = [&]() {
+      const double ng[3] = {-g[0], -g[1], -g[2]};
+      double qg[4];
+      quat_plus(q, ng, qg);
+      double mx = 0.0;
+      for (int k = 0; k < 4; ++k) mx = fmax(mx, fabs(q[k] - qg[k]));
+      for (int k = 0; k < 3; ++k) mx = fmax(mx, fabs(g[3 + k]));
+      return mx;
+    };
     double gmax = gradient_max();
     auto apply_scale = [&]() {
       for (int i = 0; i < 6; ++i) { g[i] *= scale[i]; for (int j = 0; j < 6; ++j) H[i][j] *= scale[i] * scale[j]; }

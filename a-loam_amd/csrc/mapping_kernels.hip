@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256) void k_map_begin(MapArgs a) {
   MapSeq& ms = a.seq[b];
   __shared__ int s_c[3], s_cen[3];
   if (tid == 0) {
-    ms.err = 0;                                                              // capacity flags describe one step
+    if (ms.err) ms.err_steps += 1;                                           // capacity flags describe one step; what the previous step
+    ms.err = 0;                                                              // raised stays countable for a host that synchronises later
+    if (b == 0) { if (a.vox_counters[1]) a.vox_counters[3] += 1; a.vox_counters[1] = 0; }
     const OdomState& od = a.odom[b];
     double qo[4], to[3], qm[4], q[4], rt[3];
     for (int k = 0; k < 4; ++k) { qo[k] = od.q_w[k]; qm[k] = ms.q_wmap_wodom[k]; ms.q_wodom[k] = qo[k]; }
@@ -1081,6 +1083,7 @@ __global__ __launch_bounds__(256) void k_map_reserve(MapArgs a) {
           if (want < 256) want = 256;
           const int off = atomicAdd(&ms.pool_used[cls], want);
           if (off + want > a.pool_cap) {
+            atomicSub(&ms.pool_used[cls], want);                             // hand the failed reservation back
             atomicOr(&ms.err, kMapErrPool);
             add[c] = -1;                                                     // the scatter pass skips this cube
           } else {

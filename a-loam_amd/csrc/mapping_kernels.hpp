@@ -28,7 +28,8 @@ struct alignas(16) MapSeq {                              // one per sequence
   int pool_used[2];
   int err;
   int compactions;                                        // pool compactions so far (k_map_compact_*)
-  int pad[2];
+  int err_steps;                                          // earlier steps of this sequence that ended with err != 0 (folded in by k_map_begin)
+  int pad;
 };
 
 struct MapEdgeRec { double cp[3], a[3], b[3]; int valid, pad; };        // LidarEdgeFactor(curr_point, point_a, point_b, 1.0)      (:618)
@@ -51,7 +52,7 @@ struct VoxArgs {
   int* tile_seg;           // [tile_cap] owning segment of every tile
   int* tile_heads;         // [tile_cap]
   int* tile_pref;          // [tile_cap + 1]
-  int* counters;           // [0] total tiles, [1] error
+  int* counters;           // [0] total tiles, [1] error of this step, [2] merge levels needed, [3] earlier steps with an error
   unsigned long long* keys[2];
   float4* tmp;             // [key_cap]
   int* bbox;               // [n_segs][6] order-preserving ints
@@ -88,6 +89,7 @@ struct MapArgs {
   MapEdgeRec* edges;             // [B][R*120]
   MapNormRec* norms;             // [B][cap]
   int lm_max_iterations;
+  int* vox_counters;             // VoxArgs::counters: [1] capacity flag of this step's voxel filters, [3] earlier steps that raised it
 };
 constexpr int kTabInts = 256;   // [0..74] valid cube ids, [80..155] corner prefix, [160..235] surf prefix
 

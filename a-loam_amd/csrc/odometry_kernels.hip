@@ -771,9 +771,10 @@ void launch_transform_queries(const OdomArgs& a, hipStream_t s) {
   if (a.distortion) hipLaunchKernelGGL(k_transform_queries<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_transform_queries<false>, grid, dim3(256), 0, s, a);
 }
-void launch_associate(const OdomArgs& a, bool plane, int max_queries, hipStream_t s) {
+void launch_associate(const OdomArgs& a, bool plane, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
-  const dim3 grid((unsigned)(max_queries * by)), block(64);
+  const int qcap = plane ? a.R * 24 : a.R * 12;   // the kernel decodes (sequence, query) from blockIdx.x with exactly this slot count
+  const dim3 grid((unsigned)(qcap * by)), block(64);
   if (a.distortion) {
     if (plane) hipLaunchKernelGGL((k_associate<true, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_associate<false, true>), grid, block, 0, s, a);

@@ -177,26 +177,34 @@ __global__ __launch_bounds__(256) void k_classify(RegArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
-// One wave per ring (16 waves per workgroup): lanes take 64 blocks at a time, exclusive prefix by shuffles.
+// Exclusive scan over the blocks of every ring.  hist is [block][ring]: thread (chunk, ring) walks its chunk of consecutive blocks,
+// so the lanes of a wave always touch consecutive rings of one block row (coalesced; the round-2 kernel put the lanes across blocks,
+// a 256 / 512-byte stride that fetched 5 - 9 times the table at 128 rings).  Chunk totals meet in LDS, one thread per ring chains them.
 __global__ __launch_bounds__(1024) void k_ring_offsets(RegArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  __shared__ int s_chunk[1024];                       // [chunk][ring] totals -> exclusive starts of the chunks
   __shared__ int s_cnt[kMaxRings];
   const int n = a.meta[b].n_in < a.cap ? a.meta[b].n_in : a.cap;
   const int nb = (n + kBlockPts - 1) / kBlockPts;
-  for (int r = wave; r < a.R; r += 16) {
-    int carry = 0;
-    for (int base = 0; base < nb; base += 64) {
-      const int blk = base + lane;
-      const long long o = ((long long)b * a.NB + blk) * a.R + r;
-      const int h = blk < nb ? a.hist[o] : 0;
-      int incl = h;
-      for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
-      if (blk < nb) a.blockoff[o] = carry + incl - h;
-      carry += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) s_cnt[r] = carry;
+  int rp = 1;
+  while (rp < a.R) rp <<= 1;                          // rings padded to a power of two <= 128
+  const int nchunk = 1024 / rp, r = tid & (rp - 1), chunk = tid / rp;
+  const int per = (nb + nchunk - 1) / nchunk, b0 = chunk * per, b1 = min(nb, b0 + per);
+  const long long base = (long long)b * a.NB * a.R;
+  int sum = 0;
+  if (r < a.R) for (int blk = b0; blk < b1; ++blk) sum += a.hist[base + (long long)blk * a.R + r];
+  s_chunk[tid] = sum;
+  __syncthreads();
+  if (tid < a.R) {
+    int run = 0;
+    for (int c = 0; c < nchunk; ++c) { const int v = s_chunk[c * rp + tid]; s_chunk[c * rp + tid] = run; run += v; }
+    s_cnt[tid] = run;
   }
   __syncthreads();
+  if (r < a.R) {
+    int run = s_chunk[tid];
+    for (int blk = b0; blk < b1; ++blk) { const long long o = base + (long long)blk * a.R + r; const int h = a.hist[o]; a.blockoff[o] = run; run += h; }
+  }
   if (tid == 0) {
     int run = 0;
     for (int q = 0; q < a.R; ++q) { a.ringstart[b * (a.R + 1) + q] = run; run += s_cnt[q]; }
@@ -300,18 +308,26 @@ __device__ __forceinline__ unsigned wave_extreme_u32(unsigned v, int lane) {
 // workgroup publishes its own count per class as ONE 8-byte granule {launch epoch, count}: the value is its own flag, nothing has
 // to be reset between launches, and a reader needs no other data of the writer (MI355X_MICROARCH.md, inter-workgroup visibility:
 // agent-scope loads of 8-byte granules).  A reader gathers the granules of the rings in front of it with one wave (lane = ring)
-// and sums them: no serial ripple from ring to ring.  Waiting cannot deadlock: a workgroup only waits for workgroups with a lower
-// linear id, and those are dispatched first.
+// and sums them: no serial ripple from ring to ring.  A workgroup only waits for workgroups with a lower linear id, and those are
+// dispatched first on this hardware (an assumption about the dispatcher; the wait below is bounded in case it breaks).
 __device__ __forceinline__ void publish_count(unsigned long long* slot, unsigned epoch, int count) {
   __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ int gather_counts(const unsigned long long* slots, int upto, unsigned epoch, int lane) {   // whole wave
+// The wait is bounded: in-order dispatch is what makes it free today, but it is not something HIP promises, and a fault in an
+// earlier ring's workgroup must not hang the stream.  After kGatherSpinLimit polls (~1 s) the lane gives up, the count reads 0 and
+// kErrInternal is raised in the sequence's SeqMeta.err (aloam_synchronize reports it).
+constexpr int kGatherSpinLimit = 1 << 20;
+__device__ __forceinline__ int gather_counts(const unsigned long long* slots, int upto, unsigned epoch, int lane, int* err) {   // whole wave
   int sum = 0;
   for (int base = 0; base < upto; base += 64) {
     const int q = base + lane;
     if (q < upto) {
       unsigned long long g;
-      while ((unsigned)((g = __hip_atomic_load(slots + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) __builtin_amdgcn_s_sleep(1);
+      int spins = 0;
+      while ((unsigned)((g = __hip_atomic_load(slots + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != epoch) {
+        if (++spins > kGatherSpinLimit) { atomicOr(err, kErrInternal); g = 0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
       sum += (int)(unsigned)g;
     }
   }
@@ -412,7 +428,7 @@ __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, i
 template <int NPAD, typename K, int SHIFT>
 __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned char* flags, const signed char* label, int* s_scan, int* s_misc,
                                                const float4* cloud, float4* out, int L, int tid, int lane, int wave,
-                                               unsigned long long* lb_lf, int ring, int nrings, unsigned epoch) {
+                                               unsigned long long* lb_lf, int ring, int nrings, unsigned epoch, int* err) {
   const unsigned* vis = reinterpret_cast<const unsigned*>(smem);               // region A: voxel index per element [NPAD] ...
   K* rkeys = reinterpret_cast<K*>(smem);                                      // ... replaced by the run keys once the heads are known
   constexpr unsigned kEMask = SHIFT >= 32 ? 0xffffffffu : ((1u << (SHIFT & 31)) - 1u);
@@ -489,8 +505,8 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
   // earlier and have normally published long ago: the gather does not wait.
   if (wave == 0) {
     const unsigned long long* lb0 = lb_lf - 3 * nrings;
-    const int b0 = gather_counts(lb0 + 0 * nrings, ring, epoch, lane), b1 = gather_counts(lb0 + 1 * nrings, ring, epoch, lane);
-    const int b2 = gather_counts(lb0 + 2 * nrings, ring, epoch, lane), b3 = gather_counts(lb_lf, ring, epoch, lane);
+    const int b0 = gather_counts(lb0 + 0 * nrings, ring, epoch, lane, err), b1 = gather_counts(lb0 + 1 * nrings, ring, epoch, lane, err);
+    const int b2 = gather_counts(lb0 + 2 * nrings, ring, epoch, lane, err), b3 = gather_counts(lb_lf, ring, epoch, lane, err);
     if (lane == 0) { s_misc[40] = b0; s_misc[41] = b1; s_misc[42] = b2; s_misc[43] = b3; }
   }
   __syncthreads();
@@ -795,9 +811,9 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int EB = NPAD <= 2048 ? 11 : 12;                                  // bits of an element index
   float4* out = a.less_flat + (long long)b * a.cap;                          // final place: offset = less-flat points of the rings in front
   if (!ALOAM_RF_KEYS64 && (overflow || cells_in_box <= (1ll << (32 - EB))))
-    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch);
+    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err);
   else
-    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch);
+    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err);
   // the picked points go straight to their final place in the three clouds, in the reference's order (ring, sector, pick order;
   // sharp = the first two less-sharp picks, :301-311)
   if (wave == 0) {
@@ -822,8 +838,9 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
 __global__ __launch_bounds__(64) void k_cloud_sizes(RegArgs a) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const unsigned long long* lb = a.lookback + (long long)b * 4 * a.R;
-  const int n0 = gather_counts(lb + 0 * a.R, a.R, a.epoch, lane), n1 = gather_counts(lb + 1 * a.R, a.R, a.epoch, lane);
-  const int n2 = gather_counts(lb + 2 * a.R, a.R, a.epoch, lane), n3 = gather_counts(lb + 3 * a.R, a.R, a.epoch, lane);
+  int* err = &a.meta[b].err;
+  const int n0 = gather_counts(lb + 0 * a.R, a.R, a.epoch, lane, err), n1 = gather_counts(lb + 1 * a.R, a.R, a.epoch, lane, err);
+  const int n2 = gather_counts(lb + 2 * a.R, a.R, a.epoch, lane, err), n3 = gather_counts(lb + 3 * a.R, a.R, a.epoch, lane, err);
   if (lane == 0) { a.meta[b].n_sharp = n0; a.meta[b].n_less_sharp = n1; a.meta[b].n_flat = n2; a.meta[b].n_less_flat = n3; }
 }
 

@@ -13,8 +13,11 @@
  *     are independent (one per GPU / per process for multi-GPU; no collectives — sequences never exchange data).
  *     Every call runs on the context's device and restores the calling thread's current HIP device before returning.
  *   - points are 16-byte records {float x, y, z, w}; w = `intensity` of pcl::PointXYZI
- *     (reference include/aloam_velodyne/common.h:43).  Input records may use any stride >= 16 bytes
- *     (32 = the PointCloud2 point_step pcl::toROSMsg<PointXYZI> produces, reference src/kittiHelper.cpp:153-154).
+ *     (reference include/aloam_velodyne/common.h:43).  Input records may use any stride >= 16 bytes that is a multiple of 4
+ *     (16 = KITTI .bin, 32 = the PointCloud2 point_step pcl::toROSMsg<PointXYZI> produces, reference src/kittiHelper.cpp:153-154),
+ *     or stride 12 = {x, y, z} only: scan registration never reads the 4th float of its input (it overwrites intensity with
+ *     scanID + relTime, reference src/scanRegistration.cpp:132-133,239), so a driver may leave it off the wire (a quarter less
+ *     PCIe traffic for the host-fed entries).  Not with ring_from_field, which IS the 4th float.
  *   - quaternions are (x, y, z, w) like para_q (reference src/laserOdometry.cpp:96-100).
  *   - there is NO CPU fallback: every entry point fails with ALOAM_E_HIP if the HIP runtime / a gfx950 device
  *     is unavailable.
@@ -34,8 +37,9 @@ enum {
   ALOAM_E_SCAN_LINES = -2, /* n_scans not 16/32/64 without ring_from_field (reference src/scanRegistration.cpp:472-476) */
   ALOAM_E_EMPTY = -3,      /* no point of some scan survives the NaN / minimum-range filter */
   ALOAM_E_CAPACITY = -4,   /* a scan exceeds max_points, a ring exceeds max_ring_points, or (mapping) the map pool / voxel scratch was too small
-                              for the last step: that step has still run, the points that did not fit are missing from the map */
-  ALOAM_E_HIP = -5,        /* HIP runtime error / no device */
+                              in some step since the last aloam_synchronize: the steps have still run, the points that did not fit are
+                              missing from the map */
+  ALOAM_E_HIP = -5,        /* HIP runtime error / no device / internal device-side time-out */
   ALOAM_E_STATE = -6       /* call order (e.g. odometry before any registration) */
 };
 
@@ -95,7 +99,9 @@ int aloam_scan_register(aloam_ctx* ctx, const void* const* scans, const int* n_i
 /* Device-resident input: sequence b starts at d_scans + b * seq_stride_bytes.  Fully asynchronous.           */
 int aloam_scan_register_device(aloam_ctx* ctx, const void* d_scans, long long seq_stride_bytes, const int* n_in, int stride_bytes);
 
-/* Host-resident batch in ONE buffer (sequence b at h_scans + b * seq_stride_bytes): what a driver thread that receives the
+/* Host-resident batch in ONE buffer (sequence b at h_scans + b * seq_stride_bytes, n_in[b] * stride_bytes readable bytes each;
+ * rows 0 .. batch-2 are copied with the batch-wide maximum length, which stays inside the buffer because another row follows):
+ * what a driver thread that receives the
  * sensor messages (reference src/scanRegistration.cpp:114-133) hands over.  One batched H2D copy per call on a dedicated copy
  * stream into one of two device slabs, so the copy of call k + 1 runs under the kernels of call k; asynchronous when the buffer is
  * pinned (hipHostMalloc / hipHostRegister).  The buffer must stay unmodified until aloam_input_consumed() or aloam_synchronize(). */
@@ -115,8 +121,9 @@ int aloam_process_host(aloam_ctx* ctx, const void* h_scans, long long seq_stride
  * laserCloudCen*; src/laserMapping.cpp:72-116) and reads the launch parameters mapping_line_resolution / mapping_plane_resolution
  * (:898-905).  pool_points = capacity of the device-resident map per sequence and feature class.  Call once, before the first step. */
 /* Limits: the map of one sequence and class lives in pool_points points (cubes grow by doubling, the pool is compacted when
- * fragmented); one cube may hold up to the whole pool.  A frame whose points do not fit is reported by aloam_synchronize as
- * ALOAM_E_CAPACITY for that step only — the flag is reset by the next aloam_mapping_step. */
+ * fragmented); one cube may hold up to the whole pool.  Frames whose points do not fit are counted on the device; the first
+ * aloam_synchronize after such a step returns ALOAM_E_CAPACITY once (however many asynchronous steps were queued in between), then
+ * ALOAM_OK again until it happens anew. */
 int aloam_mapping_enable(aloam_ctx* ctx, float mapping_line_resolution, float mapping_plane_resolution, int pool_points);
 /* One frame for every sequence, asynchronous.  Consumes what the odometry node publishes for the frame — /laser_cloud_corner_last,
  * /laser_cloud_surf_last, /velodyne_cloud_3, /laser_odom_to_init (src/laserOdometry.cpp:508-591) — straight from the context

@@ -316,11 +316,20 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
   std::vector<double> r, J;
   double cost = pb.evaluate(q, t, &r, &J);
   sm.initial_cost = cost;
+  // Ceres' ResidualBlock::Evaluate rejects non-finite residuals / Jacobians: "Residual and Jacobian evaluation failed" -> FAILURE
+  // before the first iteration, parameters untouched (e.g. LidarEdgeFactor with a == b: 0 * inf).
+  if (!std::isfinite(cost)) { sm.termination = 5; sm.final_cost = cost; return sm; }
+  // Ceres 1.12 trust_region_minimizer.cc: gradient_max_norm = |x - Plus(x, -g)|_inf, g = J^T r of the unscaled Jacobian in the
+  // tangent space (SURVEY.md Appendix A "projected through Plus"); q, t are the current iterate when this is called.
   auto gradient_max = [&](const std::vector<double>& Ju, const std::vector<double>& ru) {
     double g[6] = {0, 0, 0, 0, 0, 0};
     for (int i = 0; i < m; ++i) for (int c = 0; c < 6; ++c) g[c] += Ju[(size_t)i * 6 + c] * ru[i];
+    const double ng[3] = {-g[0], -g[1], -g[2]};
+    double qg[4];
+    quat_plus(q, ng, qg);
     double mx = 0.0;
-    for (int c = 0; c < 6; ++c) mx = std::max(mx, std::fabs(g[c]));
+    for (int k = 0; k < 4; ++k) mx = std::max(mx, std::fabs(q[k] - qg[k]));
+    for (int k = 0; k < 3; ++k) mx = std::max(mx, std::fabs(g[3 + k]));      // t - (t - g_t)
     return mx;
   };
   double gmax = gradient_max(J, r);

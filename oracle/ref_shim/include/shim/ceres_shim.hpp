@@ -315,12 +315,22 @@ inline void Solve(const Solver::Options& o, Problem* problem, Solver::Summary* s
   if (m == 0) { sum->shim_termination = 4; sum->termination_type = CONVERGENCE; return; }
   ev.evaluate(x, &cost, &r, &J);
   sum->initial_cost = cost;
+  if (!std::isfinite(cost)) {   // ResidualBlock::Evaluate's validity check fails: FAILURE before the first iteration, x untouched
+    sum->final_cost = cost; sum->iterations = 0; sum->shim_termination = 5; sum->termination_type = FAILURE;
+    return;
+  }
   std::vector<double> scale(n, 1.0);
   if (o.jacobi_scaling) for (int c = 0; c < n; ++c) { double s = 0.0; for (int i = 0; i < m; ++i) s += J[static_cast<size_t>(i) * n + c] * J[static_cast<size_t>(i) * n + c]; scale[c] = 1.0 / (1.0 + std::sqrt(s)); }
   auto scale_jac = [&]() { for (int i = 0; i < m; ++i) for (int c = 0; c < n; ++c) J[static_cast<size_t>(i) * n + c] *= scale[c]; };
-  auto grad_max = [&]() {   // max-norm of the (unscaled) tangent-space gradient J^T r; J is still unscaled when this is called
+  // Ceres 1.12 trust_region_minimizer.cc: gradient_max_norm = |x - Plus(x, -g)|_inf with g = J^T r the (unscaled) tangent-space
+  // gradient; J is still unscaled when this is called.  (For a Euclidean block this is |g|_inf; for the quaternion block the
+  // step goes through the parameterization.)
+  auto grad_max = [&]() {
+    std::vector<double> ng(n), xg;
+    for (int c = 0; c < n; ++c) { double g = 0.0; for (int i = 0; i < m; ++i) g += J[static_cast<size_t>(i) * n + c] * r[i]; ng[c] = -g; }
+    ev.plus(x, ng, &xg);
     double mx = 0.0;
-    for (int c = 0; c < n; ++c) { double g = 0.0; for (int i = 0; i < m; ++i) g += J[static_cast<size_t>(i) * n + c] * r[i]; mx = std::max(mx, std::fabs(g)); }
+    for (size_t k = 0; k < x.size(); ++k) mx = std::max(mx, std::fabs(x[k] - xg[k]));
     return mx;
   };
   double gmax = grad_max();

@@ -7,6 +7,7 @@ import os
 
 import numpy as np
 import pytest
+import lm_scenarios
 from conftest import bits_equal, quat_angle
 
 pytestmark = pytest.mark.gpu
@@ -218,15 +219,20 @@ def test_full_size_batch_properties(O, binding, syn):
             counts[b, k] = len(s); data[b, k, :len(s)] = s
     torch.cuda.synchronize()
     gpu = _mk(binding, model, batch=B, max_points=NP, max_ring_points=2059)
-    host0 = data[0].cpu().numpy()
-    orc = O.Oracle(n_scans=64, min_range=model.min_range)
+    host = data.cpu().numpy()
+    orcs = [O.Oracle(n_scans=64, min_range=model.min_range) for _ in range(B)]
     for k in range(T):
         gpu.process_device(data.data_ptr() + k * NP * 16, T * NP * 16, counts[:, k])
         gpu.synchronize()
-        orc.scan_register(host0[k, :counts[0, k]])
-        po = orc.odometry_step()
-        _assert_pose_close(po, gpu.pose(0), k)
-        assert bits_equal(orc.cloud(O.CLOUD_SURF_LAST), gpu.cloud(binding.CLOUD_SURF_LAST, 0))
+        for b in range(B):
+            orcs[b].scan_register(host[b, k, :counts[b, k]])
+            po = orcs[b].odometry_step()
+            _assert_pose_close(po, gpu.pose(b), (b, k))
+            so_, sg_ = orcs[b].odom_stats(), gpu.odom_stats(b)
+            for key in ("corner_corr", "plane_corr", "lm_iterations", "lm_successful", "termination"):
+                assert so_[key] == sg_[key], (b, k, key, so_, sg_)
+            assert bits_equal(orcs[b].cloud(O.CLOUD_SURF_LAST), gpu.cloud(binding.CLOUD_SURF_LAST, b)), (b, k)
+            assert bits_equal(orcs[b].cloud(O.CLOUD_CORNER_LAST), gpu.cloud(binding.CLOUD_CORNER_LAST, b)), (b, k)
         for b in range(B):
             cl = gpu.cloud(binding.CLOUD_FULL, b)
             s0, c0 = gpu.ring_ranges(b)
@@ -407,3 +413,33 @@ def test_stage_sized_contexts(O, binding, sequence):
         assert e.value.code == binding.E_STATE
     for c in (full, reg, odo, mp, fullm):
         c.close()
+
+
+def test_lm_branch_coverage(O, binding, sequence):
+    """The device trust-region loop (lm_device.hpp; reference call src/laserOdometry.cpp:494-499) against the oracle on problems
+    built to leave the happy path (tests/lm_scenarios.py): bad warm starts, unobservable directions, fewer residual rows than
+    parameters (the device solves the damped normal equations by Cholesky where Ceres and the oracle use QR of the stacked
+    Jacobian: this is where the two could part), non-finite residuals.  Every scenario must give the oracle's iteration count,
+    success count, termination code and pose; and over the set every branch must actually have been taken."""
+    model, scs = lm_scenarios.build(O, sequence)
+    seen, worst = set(), 0.0
+    gpus = {}
+    for sc in scs:
+        lm, outer = sc[6], sc[7]
+        if (lm, outer) not in gpus:
+            gpus[(lm, outer)] = _mk(binding, model, max_points=40000, lm_max_iterations=lm, outer_iterations=outer)
+        orc = O.Oracle(n_scans=64, min_range=model.min_range, lm_max_iterations=lm, outer_iterations=outer)
+        so, po = lm_scenarios.run(orc, sc)
+        sg, pg = lm_scenarios.run(gpus[(lm, outer)], sc)
+        for key in ("corner_corr", "plane_corr", "lm_iterations", "lm_successful", "termination"):
+            assert so[key] == sg[key], (sc[0], key, so, sg)
+        for k in range(2):
+            a, b = so["final_cost"][k], sg["final_cost"][k]
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-9 * abs(a) + 1e-16, (sc[0], so, sg)
+        _assert_pose_close(po, pg, sc[0])
+        worst = max(worst, float(np.abs(po["t_lc"] - pg["t_lc"]).max()))
+        seen |= lm_scenarios.branches(so)
+    for g in gpus.values():
+        g.close()
+    assert {"termination0", "termination1", "termination2", "termination3", "termination5", "rejected_or_invalid"} <= seen, seen
+    print(f"lm branch coverage: {len(scs)} scenarios, branches {sorted(seen)}, worst |dt| GPU vs oracle {worst:.3g} m")

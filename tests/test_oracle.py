@@ -420,3 +420,22 @@ def test_device_atan_restatement_matches_glibc_bit_for_bit():
     assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run([os.path.join(host, "build", "test_atan_port")], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.startswith("ok "), r.stdout[-2000:]
+
+
+def test_lm_scenarios_reach_every_solver_branch(O, sequence):
+    """tests/lm_scenarios.py must drive the oracle's ceres::Solve restatement (oracle_solver.cpp; reference call
+    src/laserOdometry.cpp:494-499) through rejected steps and every termination the configuration can reach — the GPU test
+    test_lm_branch_coverage compares the device loop with the oracle on exactly these problems."""
+    import lm_scenarios
+    model, scs = lm_scenarios.build(O, sequence)
+    cover = {}
+    for sc in scs:
+        orc = O.Oracle(n_scans=64, min_range=model.min_range, lm_max_iterations=sc[6], outer_iterations=sc[7])
+        st, pose = lm_scenarios.run(orc, sc)
+        for b in lm_scenarios.branches(st):
+            cover.setdefault(b, []).append(sc[0])
+        if "degenerate" in sc[0]:      # non-finite residual: FAILURE before the first iteration, warm start untouched
+            q = np.array(sc[4]) / np.linalg.norm(sc[4])
+            assert st["termination"] == [5, 5] and st["lm_iterations"] == [0, 0] and np.allclose(pose["q_lc"], q) and np.allclose(pose["t_lc"], sc[5])
+    assert {"termination0", "termination1", "termination2", "termination3", "termination5", "rejected_or_invalid"} <= set(cover), cover.keys()
+    assert len(cover["rejected_or_invalid"]) >= 3
