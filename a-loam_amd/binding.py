@@ -176,13 +176,13 @@ class Aloam:
 
     # ---- stage 1 -------------------------------------------------------------------------------------------
     def scan_register(self, scans, check=True):
-        """scans: one float32 [N,>=4] array per sequence (or a single array when batch == 1)."""
+        """scans: one float32 [N,>=3] array per sequence (or a single array when batch == 1)."""
         if isinstance(scans, np.ndarray) and scans.ndim == 2:
             scans = [scans]
         assert len(scans) == self.batch
         arrs = [_f32(s) for s in scans]
         stride = arrs[0].strides[0] if arrs[0].shape[0] else 4 * arrs[0].shape[1]
-        assert all(a.ndim == 2 and a.shape[1] >= 4 and (a.shape[0] == 0 or a.strides[0] == stride) for a in arrs)
+        assert all(a.ndim == 2 and a.shape[1] >= 3 and (a.shape[0] == 0 or a.strides[0] == stride) for a in arrs)   # 3 columns = the 12-byte x y z wire format
         ptrs = (C.c_void_p * self.batch)(*[a.ctypes.data for a in arrs])
         nin = (C.c_int * self.batch)(*[a.shape[0] for a in arrs])
         self._check(lib().aloam_scan_register(self.h, ptrs, nin, stride))

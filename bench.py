@@ -93,6 +93,7 @@ def parse_args():
 
 # ---------------------------------------------------------------------------------------------------------------------
 SHARED_GPU_ENV = "ALOAM_BENCH_SHARED_GPU"   # test hook: let the ranks share the visible devices (control plane on gloo) on a 1-GPU box
+RANK_ENV_ONLY = "ALOAM_BENCH_RANK_ENV_ONLY"  # test hook: a started rank prints the environment it was given and exits (no GPU needed)
 
 
 def rank_envs(n, port, base=None):
@@ -104,10 +105,11 @@ def rank_envs(n, port, base=None):
 
 def self_spawn(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks here (one process per GPU)."""
-    import torch
     n = args.gpus
-    have = torch.cuda.device_count()
-    assert have >= n or os.environ.get(SHARED_GPU_ENV), f"--gpus {n} but only {have} HIP device(s) are visible"
+    if not (os.environ.get(SHARED_GPU_ENV) or os.environ.get(RANK_ENV_ONLY)):
+        import torch
+        have = torch.cuda.device_count()
+        assert have >= n, f"--gpus {n} but only {have} HIP device(s) are visible"
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -239,28 +241,45 @@ def roofline_of(prof, steps, B, sensor, mapping):
     return r
 
 
-def host_fed(torch, binding, wl, local_rank, steps, warmup, mapping=False):
-    """The same steps with every sweep crossing PCIe: the batch sits in PINNED host memory, each step is one batched H2D copy on
-    the context's copy stream into one of two device slabs, overlapped with the previous step's kernels."""
-    host = wl.data.cpu().pin_memory()
-    cx = wl.ctx(binding, wl.B, local_rank)
+def host_fed(torch, binding, wl, local_rank, steps, warmup, stride=16, contexts=2):
+    """The same steps with every sweep crossing PCIe: the batch sits in PINNED host memory, each step is one batched H2D copy per
+    context on its copy stream into one of two device slabs, overlapped with the previous step's kernels.  `stride` = bytes per
+    input record on the wire: 16 (KITTI .bin / x y z i) or 12 (x y z: the reference never reads the 4th float of its input,
+    src/scanRegistration.cpp:132-133).  The batch is split over `contexts` streams so that kernels of one half overlap launch gaps
+    and tails of the other (per-kernel events are off in this leg anyway)."""
+    NC = contexts if wl.B % contexts == 0 and wl.B >= contexts else 1
+    BC = wl.B // NC
+    src = wl.data if stride == 16 else wl.data[..., :3].contiguous()
+    host = src.cpu().pin_memory()
+    del src
+    ctxs = [wl.ctx(binding, BC, local_rank) for _ in range(NC)]
     order = frame_order(wl.T, warmup + steps)
-    nin = {k: wl.nin(k) for k in range(wl.T)}
-    hp = host.data_ptr()
+    nin = {(k, c): wl.nin(k, c * BC, (c + 1) * BC) for k in range(wl.T) for c in range(NC)}
+    hp, seq_stride = host.data_ptr(), wl.T * wl.NP * stride
+
+    def step(k):
+        for c, cx in enumerate(ctxs):
+            cx.process_host(hp + c * BC * seq_stride + k * wl.NP * stride, seq_stride, nin[(k, c)], stride)
+
     for k in order[:warmup]:
-        cx.process_host(hp + k * wl.NP * 16, wl.seq_stride, nin[k])
-    cx.synchronize()
+        step(k)
+    for cx in ctxs:
+        cx.synchronize()
     t0 = time.perf_counter()
     for k in order[warmup:]:
-        cx.process_host(hp + k * wl.NP * 16, wl.seq_stride, nin[k])
-    cx.synchronize()
+        step(k)
+    for cx in ctxs:
+        cx.synchronize()
     el = time.perf_counter() - t0
-    cx.close()
-    bytes_per_step = float(sum(int(wl.counts[:, k].max()) for k in order[warmup:])) / steps * 16 * wl.B
+    for cx in ctxs:
+        cx.close()
+    # points that cross the link per step: every context copies its rows 0 .. BC-2 with the context-wide maximum length and the last
+    # row with its own (aloam_process_host)
+    rows = float(sum(int(wl.counts[c * BC:(c + 1) * BC, k].max()) * (BC - 1) + int(wl.counts[(c + 1) * BC - 1, k]) for c in range(NC) for k in order[warmup:])) / steps
     del host
-    return {"value": round(wl.B * steps / el, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el / steps, 4),
-            "pcie_gbs": round(bytes_per_step / (el / steps) / 1e9, 2),
-            "how": "pinned host batch, one hipMemcpy2DAsync per step on a copy stream, two device slabs (copy of step k+1 under the kernels of step k), aloam_process_host"}
+    return {"value": round(wl.B * steps / el, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el / steps, 4), "wire_bytes_per_point": stride,
+            "contexts": NC, "pcie_gbs": round(rows * stride / (el / steps) / 1e9, 2),
+            "how": "pinned host batch, one strided H2D copy per context and step on a copy stream, two device slabs each (copy of step k+1 under the kernels of step k), aloam_process_host"}
 
 
 def latency(binding, wl, local_rank, sweeps, mapping):
@@ -393,6 +412,9 @@ def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)
+    if os.environ.get(RANK_ENV_ONLY):
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")} | {"argv": sys.argv[1:]}), flush=True)
+        return
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -442,9 +464,10 @@ def main():
 
     extras = rank == 0 and world == 1 and not args.no_extras
     if extras:
-        hf = host_fed(torch, binding, wl, local_rank, args.steps, args.warmup)
-        out["value_host_input"] = hf["value"]              # per GPU, PCIe-inclusive; never the headline
+        hf = host_fed(torch, binding, wl, local_rank, args.steps, args.warmup, stride=16)
+        out["value_host_input"] = hf["value"]              # per GPU, PCIe-inclusive, the 16-byte wire format; never the headline
         out["host_input"] = hf
+        out["host_input_xyz12"] = host_fed(torch, binding, wl, local_rank, args.steps, args.warmup, stride=12)
         out["latency"] = latency(binding, wl, local_rank, args.latency_sweeps, mapping=False)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["accuracy"] = accuracy(binding, wl, local_rank)

@@ -48,3 +48,17 @@ def test_cpu_baseline_worker(tmp_path, syn):
         assert r.returncode == 0, r.stderr
         o = json.loads(r.stdout.strip().splitlines()[-1])
         assert o["scans"] >= 3 and len(o["per_scan_ms"]) == o["scans"] and o["seconds"] > 0
+
+
+def test_self_spawn_really_starts_the_ranks():
+    """`python bench.py --gpus 3` executed for real: the parent starts three children which (test hook ALOAM_BENCH_RANK_ENV_ONLY)
+    print the environment they were given and exit; no GPU and no torch involved."""
+    env = dict(os.environ, ALOAM_BENCH_RANK_ENV_ONLY="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--batch", "7", "--steps", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    ranks = sorted((json.loads(line) for line in r.stdout.strip().splitlines()), key=lambda d: int(d["RANK"]))
+    assert [d["RANK"] for d in ranks] == ["0", "1", "2"] and [d["LOCAL_RANK"] for d in ranks] == ["0", "1", "2"]
+    assert all(d["WORLD_SIZE"] == "3" and d["MASTER_ADDR"] == "127.0.0.1" and d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for d in ranks)
+    assert len({d["MASTER_PORT"] for d in ranks}) == 1 and int(ranks[0]["MASTER_PORT"]) > 0
+    assert all(d["argv"] == ["--gpus", "3", "--batch", "7", "--steps", "2"] for d in ranks)      # every rank gets the caller's flags

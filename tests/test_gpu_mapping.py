@@ -218,3 +218,35 @@ def test_map_pool_compaction(O, binding):
     assert info["compactions"] >= 1, info
     assert sum(len(v) for v in gpu.map_cubes(0).values()) > 20480            # more live points than half the pool: doubling alone could not have held them
     gpu.close()
+
+
+def test_capacity_errors_of_unsynchronised_steps_are_not_lost(binding):
+    """Asynchronous use (bench.py queues many steps and synchronises once): a step that runs out of map pool is followed by steps
+    that fit.  The per-step flag is cleared by the next step, but aloam_synchronize must still report ALOAM_E_CAPACITY — once —
+    and the map must hold the points of the steps that did fit."""
+    rng = np.random.default_rng(5)
+    gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=2, max_points=8192, lm_max_iterations=0)
+    gpu.mapping_enable(0.4, 0.8, pool_points=4096)
+
+    def frame(n_surf, seq_with_points, x0):
+        for b in range(2):
+            n = n_surf if b == seq_with_points else 0
+            surf = rng.uniform(-20, 20, (n, 4)).astype(np.float32); surf[:, 0] += x0; surf[:, 2] *= 0.01; surf[:, 3] = rng.integers(0, 16, n)
+            corner = rng.uniform(-5, 5, (min(n, 20), 4)).astype(np.float32); corner[:, 3] = rng.integers(0, 16, min(n, 20))
+            gpu.set_last(corner, surf, b); gpu.set_full_cloud(surf[:4], b); gpu.set_state([0, 0, 0, 1], [0, 0, 0], [0, 0, 0, 1.0], [0, 0, 0.0], b)
+        gpu.mapping_step()
+
+    frame(200, 1, 0.0)          # fits
+    gpu.synchronize()
+    held = sum(len(v) for v in gpu.map_cubes(1, 1).values())
+    assert held > 100
+    frame(6000, 1, 0.0)         # sequence 1: one cube would need 2 x 6000 points of a 4096-point pool -> dropped
+    frame(0, 1, 0.0)            # nothing to insert: this step clears the per-step flag
+    frame(150, 0, 0.0)          # sequence 0 fits
+    with pytest.raises(binding.AloamError) as e:
+        gpu.synchronize()
+    assert e.value.code == binding.E_CAPACITY and "sequence 1" in str(e.value)
+    gpu.synchronize()           # reported once
+    assert sum(len(v) for v in gpu.map_cubes(1, 1).values()) >= held       # the earlier map is intact
+    assert sum(len(v) for v in gpu.map_cubes(1, 0).values()) > 50           # and the later, fitting step was inserted
+    gpu.close()

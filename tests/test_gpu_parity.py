@@ -128,7 +128,15 @@ def test_input_layouts_and_nan_filter(O, binding, syn, sequence):
     wide = np.zeros((len(x), 8), np.float32); wide[:, :4] = x; wide[:, 4:] = 123.0
     gpu.scan_register(wide)
     _assert_features_equal(fo, gpu.features(), "stride32")
+    # 12-byte records (x, y, z): the reference never reads the 4th float of its input (src/scanRegistration.cpp:132-133,239)
+    gpu.scan_register(np.ascontiguousarray(x[:, :3]))
+    _assert_features_equal(fo, gpu.features(), "stride12")
     gpu.close()
+    g2 = binding.Aloam(n_scans=16, min_range=model.min_range, ring_from_field=True, max_points=40000)
+    with pytest.raises(binding.AloamError) as e:                           # ring_from_field IS the 4th float
+        g2.scan_register(np.ascontiguousarray(x[:, :3]))
+    assert e.value.code == binding.E_ARG
+    g2.close()
 
 
 def test_edge_cases(O, binding):
@@ -371,6 +379,17 @@ def test_host_batch_entry_is_double_buffered_and_matches_device_entry(O, binding
         _assert_pose_close(po, ph, b)
         assert bits_equal(g_host.cloud(binding.CLOUD_SURF_LAST, b), g_dev.cloud(binding.CLOUD_SURF_LAST, b))
         assert bits_equal(orcs[b].cloud(O.CLOUD_SURF_LAST), g_host.cloud(binding.CLOUD_SURF_LAST, b))
+    # the 12-byte wire format through the same entry: same poses bit for bit
+    host12 = data[..., :3].contiguous().cpu().pin_memory()
+    g12 = _mk(binding, model, batch=B, max_points=NP, max_ring_points=2059)
+    for k in range(T):
+        g12.process_host(host12.data_ptr() + k * NP * 12, T * NP * 12, counts[:, k], 12)
+    g12.synchronize()
+    for b in range(B):
+        for key in ("q_w", "t_w", "q_lc", "t_lc"):
+            assert np.array_equal(g12.pose(b)[key], g_dev.pose(b)[key]), (b, key)
+        assert bits_equal(g12.cloud(binding.CLOUD_SURF_LAST, b), g_dev.cloud(binding.CLOUD_SURF_LAST, b))
+    g12.close()
     # a pageable single-sequence buffer through the same entry (the runtime stages it synchronously)
     g1 = _mk(binding, model, batch=1, max_points=NP, max_ring_points=2059)
     x = np.ascontiguousarray(hn[0, 0, :counts[0, 0]])
@@ -443,3 +462,32 @@ def test_lm_branch_coverage(O, binding, sequence):
         g.close()
     assert {"termination0", "termination1", "termination2", "termination3", "termination5", "rejected_or_invalid"} <= seen, seen
     print(f"lm branch coverage: {len(scs)} scenarios, branches {sorted(seen)}, worst |dt| GPU vs oracle {worst:.3g} m")
+
+
+def test_two_rank_bench_run(binding, tmp_path):
+    """`python bench.py --gpus 2` executed for real on this box: the parent starts two ranks (one process each, rendezvous on
+    127.0.0.1), which share the single device here (ALOAM_BENCH_SHARED_GPU: gloo control plane, since RCCL refuses two ranks on one
+    device), shard 2 x 64 sequences between them without any data-path collective, and rank 0 prints the line.  Its whole-job rate
+    must be in the range of a one-rank run over the same 128 sequences; the two lines are kept under gpurun_out/ as evidence."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--frames", "3", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, ALOAM_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r2 = subprocess.run(base + ["--gpus", "2", "--batch", "64"], env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    two = json.loads(r2.stdout.strip().splitlines()[-1])
+    r1 = subprocess.run(base + ["--gpus", "1", "--batch", "128"], env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["config"]["sequences_per_gpu"] == 64
+    assert two["scaling"] == "weak" and "no collectives" in two["config"]["parallelism"]
+    assert 0.5 < two["value"] / one["value"] < 2.0, (two["value"], one["value"])
+    out_dir = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "two_rank_shared_gpu.json"), "w") as f:
+            json.dump({"how": "ALOAM_BENCH_SHARED_GPU=1 python bench.py --gpus 2 --batch 64 --steps 4 --warmup 2 --frames 3 --no-cpu-baseline --no-extras (two ranks sharing ONE MI355X, gloo control plane) next to --gpus 1 --batch 128",
+                       "two_ranks": two, "one_rank": one}, f, indent=1)
