@@ -76,6 +76,7 @@ struct aloam_ctx {
   int *d_addcnt = nullptr, *d_cursor = nullptr, *d_compact_flag = nullptr;
   float4* d_mgrid_sorted[2] = {nullptr, nullptr}; int* d_mgrid_start[2] = {nullptr, nullptr}; int* d_mgrid_cnt[2] = {nullptr, nullptr};
   MapEdgeRec* d_medges = nullptr; MapNormRec* d_mnorms = nullptr; float4* d_registered = nullptr; float4* d_knn = nullptr;
+  int* d_vox_lists = nullptr;
   VoxSeg* d_segs = nullptr; int *d_tile_seg = nullptr, *d_tile_heads = nullptr, *d_tile_pref = nullptr, *d_vox_counters = nullptr, *d_bbox = nullptr;
   unsigned long long* d_keys[2] = {nullptr, nullptr}; float4* d_voxtmp = nullptr;
   bool system_inited = false;        // reference src/laserOdometry.cpp:69
@@ -351,7 +352,7 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
                   c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
-                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag};
+                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag, c->d_vox_lists};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_nin) (void)hipHostFree(c->h_nin);
@@ -826,7 +827,7 @@ static VoxArgs vox_args(aloam_ctx* c, int n_segs, int levels) {
   VoxArgs v{};
   v.segs = c->d_segs; v.n_segs = n_segs; v.tile_seg = c->d_tile_seg; v.tile_heads = c->d_tile_heads; v.tile_pref = c->d_tile_pref;
   v.counters = c->d_vox_counters; v.keys[0] = c->d_keys[0]; v.keys[1] = c->d_keys[1]; v.tmp = c->d_voxtmp; v.bbox = c->d_bbox;
-  v.tile_cap = c->map_tile_cap; v.key_cap = c->map_key_cap; v.levels = levels;
+  v.tile_cap = c->map_tile_cap; v.key_cap = c->map_key_cap; v.levels = levels; v.lists = c->d_vox_lists;
   return v;
 }
 
@@ -877,7 +878,9 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   if ((rc = dmalloc(c, &c->d_tile_seg, (size_t)c->map_tile_cap))) return rc;
   if ((rc = dmalloc(c, &c->d_tile_heads, (size_t)c->map_tile_cap))) return rc;
   if ((rc = dmalloc(c, &c->d_tile_pref, (size_t)c->map_tile_cap + 1))) return rc;
-  if ((rc = dmalloc(c, &c->d_vox_counters, 4))) return rc;
+  if ((rc = dmalloc(c, &c->d_vox_counters, 8))) return rc;
+  if ((rc = dmalloc(c, &c->d_vox_lists, 2 * (size_t)c->map_nsegs_max))) return rc;
+  if (prepare_voxel_filter()) { c->err = "k_vox_lds: dynamic LDS size rejected"; return ALOAM_E_HIP; }
   if ((rc = dmalloc(c, &c->d_bbox, (size_t)c->map_nsegs_max * 6))) return rc;
   if ((rc = dmalloc(c, &c->d_voxtmp, (size_t)c->map_key_cap))) return rc;
   std::vector<MapSeq> init(B);
@@ -900,6 +903,7 @@ int aloam_mapping_step(aloam_ctx* c) {
   { ProfScope p(c, K_MAP_BEGIN); launch_map_begin(a, c->stream); }
   { ProfScope p(c, K_MAP_VOXEL_STACK);                                      // downSizeFilterCorner / Surf on the incoming clouds (:542-550)
     const VoxArgs v = vox_args(c, c->B * 2, c->map_levels);
+    HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 3 * sizeof(int), c->stream));   // general-path count, the two LDS-filter lists
     launch_map_stack_segments(a, v, c->stream);
     launch_voxel_filter(v, c->map_tile_bound[0], c->stream); }
   { ProfScope p(c, K_MAP_GRID); launch_map_grid(a, c->stream); }            // kdtree*FromMap->setInputCloud (:558-559)
@@ -910,6 +914,7 @@ int aloam_mapping_step(aloam_ctx* c) {
   { ProfScope p(c, K_MAP_INSERT); launch_map_insert(a, c->d_voxtmp, c->stream); }        // :737-783
   { ProfScope p(c, K_MAP_VOXEL_CUBES);                                      // per-cube re-filter (:788-801)
     const VoxArgs v = vox_args(c, c->B * 2 * kMapValidMax, c->map_cube_levels);
+    HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 3 * sizeof(int), c->stream));
     launch_map_cube_segments(a, v, c->stream);
     launch_voxel_filter(v, c->map_tile_bound[1], c->stream); }
   { ProfScope p(c, K_MAP_REGISTER); launch_map_register(a, c->stream); }    // :836-846

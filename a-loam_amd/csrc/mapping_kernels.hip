@@ -231,6 +231,15 @@ __global__ __launch_bounds__(256) void k_map_begin(MapArgs a) {
 // =======================================================================================================
 // pcl::VoxelGrid for any number of independent segments
 // =======================================================================================================
+// Which filter takes a segment: the single-workgroup LDS filter (k_vox_lds; list 0: <= kVoxSmallN points, 256 threads; list 1: up to
+// kVoxBigN points, 1024 threads) or, for anything larger, the general tile-sort / rank-merge path through global memory.
+__device__ __forceinline__ void vox_enlist(const VoxArgs& v, int seg, int n) {
+  if (n <= 0) return;
+  if (n <= kVoxSmallN) v.lists[atomicAdd(&v.counters[5], 1)] = seg;
+  else if (n <= kVoxBigN) v.lists[v.n_segs + atomicAdd(&v.counters[6], 1)] = seg;
+  else atomicAdd(&v.counters[4], 1);
+}
+
 __global__ void k_map_stack_segments(MapArgs a, VoxArgs v) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= a.B * 2) return;
@@ -244,6 +253,8 @@ __global__ void k_map_stack_segments(MapArgs a, VoxArgs v) {
   s.final_count = nullptr;
   s.leaf = cls == 0 ? a.line_res : a.plane_res;                             // downSizeFilterCorner / Surf (:904-905)
   v.segs[g] = s;
+  vox_enlist(v, g, s.n);
+  if (s.n == 0) *s.out_count = 0;
 }
 
 __global__ void k_map_cube_segments(MapArgs a, VoxArgs v) {
@@ -258,13 +269,16 @@ __global__ void k_map_cube_segments(MapArgs a, VoxArgs v) {
     s.n = d->cnt;
     s.final_out = a.pool[cls] + (long long)b * a.pool_cap + d->off;
     s.final_count = &d->cnt;
+    s.out = v.tmp + ((long long)b * 2 + cls) * a.pool_cap + d->off;         // staging of the in-place filter: the cube's own range of a pool-sized scratch
   }
   v.segs[g] = s;
+  vox_enlist(v, g, s.n);
 }
 
 // key offsets, tile work list, bounding-box reset.  One 1024-thread workgroup.
 __global__ __launch_bounds__(1024) void k_vox_setup(VoxArgs v) {
   const int tid = threadIdx.x;
+  if (v.counters[4] == 0) { if (tid == 0) { v.counters[0] = 0; v.counters[2] = 0; } return; }   // the LDS filter took every segment
   __shared__ long long s_keys[1024];
   __shared__ int s_tiles[1024];
   const int per = (v.n_segs + 1023) / 1024;
@@ -469,6 +483,7 @@ __global__ __launch_bounds__(256) void k_vox_heads(VoxArgs v) {
 // exclusive prefix of the head counts over all tiles (one 1024-thread workgroup), per-segment output counts
 __global__ __launch_bounds__(1024) void k_vox_scan(VoxArgs v) {
   const int tid = threadIdx.x;
+  if (v.counters[4] == 0) return;
   const int n = v.counters[0];
   __shared__ int s_part[1024];
   const int per = (n + 1023) / 1024;
@@ -572,6 +587,231 @@ __global__ __launch_bounds__(256) void k_vox_copyback(VoxArgs v) {
   const int t = gt - sg.tile0;
   const int m = v.tile_pref[min(sg.tile0 + sg.ntiles, v.counters[0])] - v.tile_pref[sg.tile0];
   for (int e = tid; e < kVoxTile; e += 256) { const int i = t * kVoxTile + e; if (i < m) sg.final_out[i] = sg.out[i]; }
+  }
+}
+
+// =======================================================================================================
+// pcl::VoxelGrid of ONE segment by ONE workgroup, sorted in LDS
+// =======================================================================================================
+// The general path above sorts (voxel, point) keys through global memory: tile sort + up to log2(tiles) rank-merge launches +
+// heads + scan + emit.  The clouds the mapping stage filters are small enough for one workgroup each — the incoming less-sharp /
+// less-flat clouds (6 k / 40 k points) and the map cubes (a few thousand points) — so this kernel does the whole filter of a
+// segment in one launch:
+//   pass 1  bounding box (f32 min / max, as PCL computes it) and RUN heads: a point starts a run when its 0.8 / 0.4 m cell differs
+//           from its predecessor's.  The cell test uses floor(p * inv) itself, which does not depend on the box.  The incoming
+//           clouds are ring-ordered, so consecutive points mostly share a cell: 40 k less-flat points are ~18 k runs.
+//   pass 2  one key per run: (voxel index [32 bits] , first point [16 bits]) in two LDS arrays, in input order
+//   sort    bitonic network on the pairs -> runs of one voxel adjacent and in ascending point order
+//   heads   first run of every voxel -> output rank = ascending voxel index
+//   sums    the head of a voxel walks its runs: members are added in input order, exactly what the general path (and the oracle's
+//           canonical order) does; centroid = sums / count
+// A segment whose runs do not fit (kVox*Runs), whose coordinates exceed the range where floor(p * inv) is an exact f32 integer
+// below 2^23, or that is larger than the list limits falls through to the general path untouched (counters[4]).
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_pairs(unsigned* hi, unsigned short* lo, int n, int tid) {
+  auto cx = [&](int i, int l) {
+    const unsigned hi_i = hi[i], hi_l = hi[l];
+    const unsigned short lo_i = lo[i], lo_l = lo[l];
+    if (hi_i > hi_l || (hi_i == hi_l && lo_i > lo_l)) { hi[i] = hi_l; hi[l] = hi_i; lo[i] = lo_l; lo[l] = lo_i; }
+  };
+  const int npad = pow2ceil(n);
+  for (int k = 2; k <= npad; k <<= 1) {
+    const int hk = k >> 1;
+    for (int t = tid; t < (npad >> 1); t += NT) {                           // flip stage: i <-> block_end - i (all-ascending network:
+      const int base = (t / hk) * k, off = t & (hk - 1);                     // the slots n .. npad-1 stay imaginary +inf)
+      const int i = base + off, l = base + (k - 1 - off);
+      if (l < n) cx(i, l);
+    }
+    __syncthreads();
+    for (int j = k >> 2; j > 0; j >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += NT) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        if (i + j < n) cx(i, i + j);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int NT, int CAPR, int CAPN>
+__global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
+  constexpr int NW = NT / 64, ITS = CAPR / NT, U = 4;
+  static_assert(CAPR % NT == 0 && CAPN % 64 == 0 && CAPN <= 65536 && NW <= 16, "geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char vl_smem[];
+  unsigned* khi = reinterpret_cast<unsigned*>(vl_smem);                      // [CAPR] voxel index of a run
+  unsigned short* klo = reinterpret_cast<unsigned short*>(khi + CAPR);       // [CAPR] first point of the run
+  unsigned* cont = reinterpret_cast<unsigned*>(klo + CAPR);                  // [CAPN / 32] bit i: point i continues the run of i - 1
+  int* s_tab = reinterpret_cast<int*>(cont + CAPN / 32);                     // [ITS * NW + 1] voxel heads per (round, wave) -> offsets
+  int* s_i = s_tab + ITS * NW + 1;                                           // [48] per-wave run counts / flags
+  float* s_f = reinterpret_cast<float*>(s_i + 48);                           // [6][NW] bounding-box partials
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int* list = v.lists + (long long)which * v.n_segs;
+  const int count = v.counters[5 + which];
+  for (int li = blockIdx.x; li < count; li += gridDim.x) {
+    __syncthreads();                                                         // LDS is reused from segment to segment
+    const int s = list[li];
+    const VoxSeg sg = v.segs[s];
+    const int n = sg.n;
+    const float4* in = sg.in;
+    const float inv = 1.0f / sg.leaf;
+    const int chunk = ((n + NW - 1) / NW + 63) & ~63;                        // every wave owns a contiguous, 64-aligned stretch of the segment
+    const int w0 = wave * chunk, w1 = min(n, w0 + chunk);
+    // ---- pass 1: bounding box, run heads ------------------------------------------------------------------------------------
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    int heads = 0;
+    bool big = false;
+    float cfx = 0.f, cfy = 0.f, cfz = 0.f;                                   // cell of the point in front of this row (lane 0's predecessor)
+    if (w0 < w1 && w0 > 0) { const float4 p = in[w0 - 1]; cfx = floorf(p.x * inv); cfy = floorf(p.y * inv); cfz = floorf(p.z * inv); }
+    for (int base = w0; base < w1; base += 64 * U) {
+      float4 p[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int i = base + u * 64 + lane; p[u] = in[i < w1 ? i : w1 - 1]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rb = base + u * 64, i = rb + lane;
+        if (rb >= w1) break;                                                 // uniform
+        const bool act = i < w1;
+        const float fx = floorf(p[u].x * inv), fy = floorf(p[u].y * inv), fz = floorf(p[u].z * inv);
+        if (act) {
+          mn[0] = fminf(mn[0], p[u].x); mx[0] = fmaxf(mx[0], p[u].x);
+          mn[1] = fminf(mn[1], p[u].y); mx[1] = fmaxf(mx[1], p[u].y);
+          mn[2] = fminf(mn[2], p[u].z); mx[2] = fmaxf(mx[2], p[u].z);
+          if (!(fabsf(fx) < 8388608.f && fabsf(fy) < 8388608.f && fabsf(fz) < 8388608.f)) big = true;
+        }
+        // predecessor's cell: wave_shr:1 on the DPP network, lane 0 keeps `old` = the carried cell
+        const float px = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(cfx), __float_as_int(fx), 0x138, 0xF, 0xF, false));
+        const float py = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(cfy), __float_as_int(fy), 0x138, 0xF, 0xF, false));
+        const float pz = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(cfz), __float_as_int(fz), 0x138, 0xF, 0xF, false));
+        const bool head = act && (i == 0 || fx != px || fy != py || fz != pz);
+        const unsigned long long hm = __ballot(head), am = __ballot(act), cm = am & ~hm;
+        heads += __popcll(hm);
+        if (lane == 0) cont[rb >> 5] = (unsigned)cm;
+        if (lane == 1) cont[(rb >> 5) + 1] = (unsigned)(cm >> 32);
+        cfx = __shfl(fx, 63, 64); cfy = __shfl(fy, 63, 64); cfz = __shfl(fz, 63, 64);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      for (int d = 32; d > 0; d >>= 1) { mn[q] = fminf(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = fmaxf(mx[q], __shfl_down(mx[q], d, 64)); }
+      if (lane == 0) { s_f[q * NW + wave] = mn[q]; s_f[(3 + q) * NW + wave] = mx[q]; }
+    }
+    const bool anybig = __ballot(big) != 0ull;
+    if (lane == 0) { s_i[wave] = heads; s_i[16 + wave] = anybig ? 1 : 0; }
+    __syncthreads();
+    float gmn[3], gmx[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      gmn[q] = s_f[q * NW]; gmx[q] = s_f[(3 + q) * NW];
+#pragma unroll 1
+      for (int w = 1; w < NW; ++w) { gmn[q] = fminf(gmn[q], s_f[q * NW + w]); gmx[q] = fmaxf(gmx[q], s_f[(3 + q) * NW + w]); }
+    }
+    int n_runs = 0, rank = 0;
+    bool unfit = false;
+#pragma unroll 1
+    for (int w = 0; w < NW; ++w) { if (w == wave) rank = n_runs; n_runs += s_i[w]; unfit = unfit || s_i[16 + w] != 0; }
+    unfit = unfit || n_runs > CAPR || n > CAPN;
+    if (unfit) {                                                             // general path (uniform decision; the segment stays as it is)
+      if (tid == 0) atomicAdd(&v.counters[4], 1);
+      continue;
+    }
+    float4* const stage = sg.out;                                            // final place (stacks) or the staging range (in-place cube filter)
+    const long long dx = (long long)((gmx[0] - gmn[0]) * inv) + 1, dy = (long long)((gmx[1] - gmn[1]) * inv) + 1, dz = (long long)((gmx[2] - gmn[2]) * inv) + 1;
+    int n_vox = 0;
+    if (dx * dy * dz > 2147483647ll) {                                       // PCL's overflow guard: the input comes back unfiltered
+      n_vox = n;
+      if (!sg.final_out) for (int i = tid; i < n; i += NT) stage[i] = in[i];
+    } else {
+      int divb[3];
+      float fminb[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int minb = (int)floorf(gmn[q] * inv);
+        divb[q] = (int)floorf(gmx[q] * inv) - minb + 1;
+        fminb[q] = (float)minb;
+      }
+      // ---- pass 2: one (voxel index, first point) key per run, in input order ------------------------------------------------
+      for (int base = w0; base < w1; base += 64 * U) {
+        float4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int i = base + u * 64 + lane; p[u] = in[i < w1 ? i : w1 - 1]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int rb = base + u * 64, i = rb + lane;
+          if (rb >= w1) break;
+          const bool head = i < w1 && !((cont[i >> 5] >> (i & 31)) & 1u);
+          const unsigned long long hm = __ballot(head);
+          if (head) {
+            const int i0 = (int)(floorf(p[u].x * inv) - fminb[0]), i1 = (int)(floorf(p[u].y * inv) - fminb[1]), i2 = (int)(floorf(p[u].z * inv) - fminb[2]);
+            const int r = rank + __popcll(hm & lt);
+            khi[r] = (unsigned)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]);
+            klo[r] = (unsigned short)i;
+          }
+          rank += __popcll(hm);
+        }
+      }
+      __syncthreads();
+      bitonic_sort_pairs<NT>(khi, klo, n_runs, tid);
+      // ---- voxel heads among the sorted runs -> output rank ---------------------------------------------------------------------
+      const int rounds = (n_runs + NT - 1) / NT;                             // rounds of NT sorted runs that hold any
+      for (int it = 0; it < rounds; ++it) {
+        const int p = it * NT + tid;
+        const bool h = p < n_runs && (p == 0 || khi[p - 1] != khi[p]);
+        const unsigned long long m = __ballot(h);
+        if (lane == 0) s_tab[it * NW + wave] = __popcll(m);
+      }
+      for (int e = rounds * NW + tid; e < ITS * NW; e += NT) s_tab[e] = 0;
+      __syncthreads();
+      if (wave == 0) {                                                       // exclusive scan of the ITS * NW counts by one wave
+        constexpr int PER = (ITS * NW + 63) / 64;
+        int loc[PER], sum = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int e = lane * PER + k; loc[k] = e < ITS * NW ? s_tab[e] : 0; sum += loc[k]; }
+        const int inc = wave_scan_i32<false>(sum);
+        int run = inc - sum;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { const int e = lane * PER + k; if (e < ITS * NW) s_tab[e] = run; run += loc[k]; }
+        if (lane == 63) s_tab[ITS * NW] = inc;
+      }
+      __syncthreads();
+      n_vox = s_tab[ITS * NW];
+      // ---- centroids: the members of a voxel in input order (runs ascending, points of a run consecutive) ----------------------
+#pragma unroll 1
+      for (int it = 0; it < rounds; ++it) {
+        const int p = it * NT + tid;
+        const bool h = p < n_runs && (p == 0 || khi[p - 1] != khi[p]);
+        const int vrank = __popcll(__ballot(h) & lt);                        // (the ballot again instead of 20 registers carried across the scan)
+        if (!h) continue;
+        const unsigned vi = khi[p];
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+        int cnt = 0;
+        for (int q = p; q < n_runs && khi[q] == vi; ++q) {
+          int e = klo[q];
+          // length of the run: the continuation bits that follow its first point
+          int len = 1;
+          while (e + len < n && ((cont[(e + len) >> 5] >> ((e + len) & 31)) & 1u)) ++len;
+          for (int o = 0; o < len; o += 4) {                                 // four independent loads, added in order
+            float4 pt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pt[k] = in[e + (o + k < len ? o + k : o)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (o + k < len) { sx += pt[k].x; sy += pt[k].y; sz += pt[k].z; si += pt[k].w; }
+          }
+          cnt += len;
+        }
+        const float fc = (float)cnt;
+        stage[s_tab[it * NW + wave] + vrank] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+      }
+    }
+    if (sg.final_out) {                                                      // in-place filter: back over the cube once every member has been read
+      __syncthreads();
+      if (stage != sg.final_out && !(dx * dy * dz > 2147483647ll)) for (int i = tid; i < n_vox; i += NT) sg.final_out[i] = stage[i];
+    }
+    if (tid == 0) {
+      if (sg.final_count) *sg.final_count = n_vox; else if (sg.out_count) *sg.out_count = n_vox;
+      VoxSeg& g = v.segs[s];                                                 // consumed: the general path sees an empty segment
+      g.n = 0; g.out_count = nullptr; g.final_out = nullptr; g.final_count = nullptr;
+    }
   }
 }
 
@@ -1164,12 +1404,23 @@ void launch_map_stack_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s
 void launch_map_cube_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s) {
   hipLaunchKernelGGL(k_map_cube_segments, dim3((a.B * 2 * kMapValidMax + 255) / 256), dim3(256), 0, s, a, v);
 }
+constexpr int kVoxSmallRuns = 8192, kVoxBigRuns = 20480;
+constexpr size_t vox_lds_bytes(int nt, int capr, int capn) { return (size_t)capr * 6 + (size_t)capn / 8 + sizeof(int) * ((size_t)(capr / nt) * (nt / 64) + 1 + 48) + sizeof(float) * 6 * (nt / 64) + 64; }
+int prepare_voxel_filter() {     // the 1024-thread instance needs > 64 KiB of dynamic LDS (attribute of the function on the current device)
+  return hipFuncSetAttribute((const void*)k_vox_lds<1024, kVoxBigRuns, kVoxBigN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)vox_lds_bytes(1024, kVoxBigRuns, kVoxBigN)) == hipSuccess ? 0 : -1;
+}
 void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
-  if (tile_bound > 8192) tile_bound = 8192;            // the kernels stride over the device-side tile list
+  // single-workgroup LDS filter first (grid-stride over the two device-built lists) ...
+  const int nsmall = v.n_segs < 4096 ? v.n_segs : 4096, nbig = v.n_segs < 1024 ? v.n_segs : 1024;
+  hipLaunchKernelGGL((k_vox_lds<1024, kVoxBigRuns, kVoxBigN>), dim3(nbig), dim3(1024), vox_lds_bytes(1024, kVoxBigRuns, kVoxBigN), s, v, 1);
+  hipLaunchKernelGGL((k_vox_lds<256, kVoxSmallRuns, kVoxSmallN>), dim3(nsmall), dim3(256), vox_lds_bytes(256, kVoxSmallRuns, kVoxSmallN), s, v, 0);
+  // ... then the general path for whatever did not fit: every kernel returns at once when counters[4] == 0 (no tiles)
+  if (tile_bound > 1024) tile_bound = 1024;            // the kernels stride over the device-side tile list
   hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(1024), 0, s, v);
   hipLaunchKernelGGL(k_vox_bbox, dim3(tile_bound), dim3(256), 0, s, v);
   hipLaunchKernelGGL(k_vox_keys_sort, dim3(tile_bound), dim3(256), 0, s, v);
-  for (int level = 0; level < v.levels; ++level) hipLaunchKernelGGL(k_vox_merge, dim3(tile_bound < 4096 ? tile_bound : 4096), dim3(256), 0, s, v, level);
+  for (int level = 0; level < v.levels; ++level) hipLaunchKernelGGL(k_vox_merge, dim3(tile_bound), dim3(256), 0, s, v, level);
   hipLaunchKernelGGL(k_vox_heads, dim3(tile_bound), dim3(256), 0, s, v);
   hipLaunchKernelGGL(k_vox_scan, dim3(1), dim3(1024), 0, s, v);
   hipLaunchKernelGGL(k_vox_emit, dim3(tile_bound), dim3(256), 0, s, v);

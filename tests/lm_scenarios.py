@@ -49,9 +49,10 @@ def build(O, sequence):
                 for name, (q, tt) in (("good", GOOD), ("bad", BAD)):
                     out.append((f"sub-s{seed}-c{ns}-p{nf}-{'ground' if g else 'any'}-{name}-lm{lm}", subset(ns, nf, g, seed), corner, surf, q, tt, lm, 2))
     # every last corner point repeated in the next ring: closest point and its adjacent-ring neighbour coincide -> |a - b| = 0
-    dup = corner.copy()
+    part = corner[:3600]                                            # twice that stays inside the 120-per-ring capacity of a corner cloud
+    dup = part.copy()
     dup[:, 3] += 1.0
-    both = _ring_sorted(np.concatenate([corner, dup]))
+    both = _ring_sorted(np.concatenate([part, dup]))
     both = both[both[:, 3] < 63.9]
     for lm in (4, 8):
         out.append((f"degenerate-edges-lm{lm}", f2, both, surf, GOOD[0], GOOD[1], lm, 2))

@@ -225,24 +225,24 @@ def test_capacity_errors_of_unsynchronised_steps_are_not_lost(binding):
     that fit.  The per-step flag is cleared by the next step, but aloam_synchronize must still report ALOAM_E_CAPACITY — once —
     and the map must hold the points of the steps that did fit."""
     rng = np.random.default_rng(5)
-    gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=2, max_points=8192, lm_max_iterations=0)
+    gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=2, max_points=16384, lm_max_iterations=0)
     gpu.mapping_enable(0.4, 0.8, pool_points=4096)
 
-    def frame(n_surf, seq_with_points, x0):
+    def frame(n_surf, seq_with_points, half):
         for b in range(2):
             n = n_surf if b == seq_with_points else 0
-            surf = rng.uniform(-20, 20, (n, 4)).astype(np.float32); surf[:, 0] += x0; surf[:, 2] *= 0.01; surf[:, 3] = rng.integers(0, 16, n)
+            surf = rng.uniform(-half, half, (n, 4)).astype(np.float32); surf[:, 2] *= 0.01; surf[:, 3] = rng.integers(0, 16, n)
             corner = rng.uniform(-5, 5, (min(n, 20), 4)).astype(np.float32); corner[:, 3] = rng.integers(0, 16, min(n, 20))
             gpu.set_last(corner, surf, b); gpu.set_full_cloud(surf[:4], b); gpu.set_state([0, 0, 0, 1], [0, 0, 0], [0, 0, 0, 1.0], [0, 0, 0.0], b)
         gpu.mapping_step()
 
-    frame(200, 1, 0.0)          # fits
+    frame(200, 1, 20.0)         # fits
     gpu.synchronize()
     held = sum(len(v) for v in gpu.map_cubes(1, 1).values())
     assert held > 100
-    frame(6000, 1, 0.0)         # sequence 1: one cube would need 2 x 6000 points of a 4096-point pool -> dropped
-    frame(0, 1, 0.0)            # nothing to insert: this step clears the per-step flag
-    frame(150, 0, 0.0)          # sequence 0 fits
+    frame(14000, 1, 40.0)       # sequence 1: ~7000 occupied 0.8 m voxels on an 80 m square, more than the 4096-point pool holds even packed -> dropped
+    frame(0, 1, 20.0)           # nothing to insert: this step clears the per-step flag
+    frame(150, 0, 20.0)         # sequence 0 fits
     with pytest.raises(binding.AloamError) as e:
         gpu.synchronize()
     assert e.value.code == binding.E_CAPACITY and "sequence 1" in str(e.value)
