@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,6 +84,7 @@ struct aloam_ctx {
   bool have_features = false;
   // profiling
   bool prof_on = false;
+  bool debug_sync = false;           // environment ALOAM_DEBUG_SYNC, read once at creation
   std::vector<ProfRec> prof_pending;
   std::vector<hipEvent_t> prof_free;
   double prof_ms[K_COUNT] = {0};
@@ -120,6 +122,10 @@ struct ProfScope {
   }
   ~ProfScope() {
     if (c->prof_on) { hipEvent_t e1 = prof_event(c); (void)hipEventRecord(e1, c->stream); c->prof_pending.push_back({k, e0, e1}); }
+    if (c->debug_sync) {   // ALOAM_DEBUG_SYNC=1: wait after every stage and name it, so that a device fault can be pinned on a kernel
+      const hipError_t e = hipStreamSynchronize(c->stream);
+      std::fprintf(stderr, "[aloam] %-22s %s\n", kKernelNames[k], e == hipSuccess ? "ok" : hipGetErrorString(e));
+    }
   }
 };
 // Every entry point runs on the context's device whatever the calling thread's current device is, and leaves the caller's
@@ -254,6 +260,7 @@ int aloam_create_stages(const aloam_config* cfg, int stages, aloam_ctx** out) {
   aloam_ctx* c = new aloam_ctx();
   c->cfg = *cfg;
   c->stages = stages;
+  { const char* e = std::getenv("ALOAM_DEBUG_SYNC"); c->debug_sync = e && e[0] == '1'; }
   *out = c;   // returned even on failure so that aloam_last_error() works; caller destroys it
   if ((stages & ~ALOAM_STAGE_ALL) || !(stages & ALOAM_STAGE_ALL)) { c->err = "stages must be a non-empty combination of ALOAM_STAGE_*"; return ALOAM_E_ARG; }
   if (cfg->batch < 1 || cfg->max_points < 32 || cfg->max_points > 400000 || cfg->lm_max_iterations < 0 || cfg->outer_iterations < 1 ||
@@ -879,8 +886,9 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   if ((rc = dmalloc(c, &c->d_tile_heads, (size_t)c->map_tile_cap))) return rc;
   if ((rc = dmalloc(c, &c->d_tile_pref, (size_t)c->map_tile_cap + 1))) return rc;
   if ((rc = dmalloc(c, &c->d_vox_counters, 8))) return rc;
-  if ((rc = dmalloc(c, &c->d_vox_lists, 2 * (size_t)c->map_nsegs_max))) return rc;
+  if ((rc = dmalloc(c, &c->d_vox_lists, 3 * (size_t)c->map_nsegs_max))) return rc;
   if (prepare_voxel_filter()) { c->err = "k_vox_lds: dynamic LDS size rejected"; return ALOAM_E_HIP; }
+  if (prepare_map_grid(c->map_H[0])) { c->err = "k_mapgrid_build: dynamic LDS size rejected"; return ALOAM_E_HIP; }
   if ((rc = dmalloc(c, &c->d_bbox, (size_t)c->map_nsegs_max * 6))) return rc;
   if ((rc = dmalloc(c, &c->d_voxtmp, (size_t)c->map_key_cap))) return rc;
   std::vector<MapSeq> init(B);
@@ -903,7 +911,7 @@ int aloam_mapping_step(aloam_ctx* c) {
   { ProfScope p(c, K_MAP_BEGIN); launch_map_begin(a, c->stream); }
   { ProfScope p(c, K_MAP_VOXEL_STACK);                                      // downSizeFilterCorner / Surf on the incoming clouds (:542-550)
     const VoxArgs v = vox_args(c, c->B * 2, c->map_levels);
-    HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 3 * sizeof(int), c->stream));   // general-path count, the two LDS-filter lists
+    HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 4 * sizeof(int), c->stream));   // general-path count, the two LDS-filter lists
     launch_map_stack_segments(a, v, c->stream);
     launch_voxel_filter(v, c->map_tile_bound[0], c->stream); }
   { ProfScope p(c, K_MAP_GRID); launch_map_grid(a, c->stream); }            // kdtree*FromMap->setInputCloud (:558-559)
@@ -914,7 +922,7 @@ int aloam_mapping_step(aloam_ctx* c) {
   { ProfScope p(c, K_MAP_INSERT); launch_map_insert(a, c->d_voxtmp, c->stream); }        // :737-783
   { ProfScope p(c, K_MAP_VOXEL_CUBES);                                      // per-cube re-filter (:788-801)
     const VoxArgs v = vox_args(c, c->B * 2 * kMapValidMax, c->map_cube_levels);
-    HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 3 * sizeof(int), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 4 * sizeof(int), c->stream));
     launch_map_cube_segments(a, v, c->stream);
     launch_voxel_filter(v, c->map_tile_bound[1], c->stream); }
   { ProfScope p(c, K_MAP_REGISTER); launch_map_register(a, c->stream); }    // :836-846

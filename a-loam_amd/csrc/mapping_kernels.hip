@@ -231,11 +231,13 @@ __global__ __launch_bounds__(256) void k_map_begin(MapArgs a) {
 // =======================================================================================================
 // pcl::VoxelGrid for any number of independent segments
 // =======================================================================================================
-// Which filter takes a segment: the single-workgroup LDS filter (k_vox_lds; list 0: <= kVoxSmallN points, 256 threads; list 1: up to
-// kVoxBigN points, 1024 threads) or, for anything larger, the general tile-sort / rank-merge path through global memory.
+// Which filter takes a segment: the single-workgroup LDS filter (k_vox_lds; list 2: <= kVoxTinyN points, one wave; list 0: <= kVoxSmallN
+// points, 256 threads; list 1: up to kVoxBigN points, 1024 threads) or, for anything larger, the general tile-sort / rank-merge path
+// through global memory.
 __device__ __forceinline__ void vox_enlist(const VoxArgs& v, int seg, int n) {
   if (n <= 0) return;
-  if (n <= kVoxSmallN) v.lists[atomicAdd(&v.counters[5], 1)] = seg;
+  if (n <= kVoxTinyN) v.lists[2 * (long long)v.n_segs + atomicAdd(&v.counters[7], 1)] = seg;
+  else if (n <= kVoxSmallN) v.lists[atomicAdd(&v.counters[5], 1)] = seg;
   else if (n <= kVoxBigN) v.lists[v.n_segs + atomicAdd(&v.counters[6], 1)] = seg;
   else atomicAdd(&v.counters[4], 1);
 }
@@ -607,32 +609,90 @@ __global__ __launch_bounds__(256) void k_vox_copyback(VoxArgs v) {
 //           canonical order) does; centroid = sums / count
 // A segment whose runs do not fit (kVox*Runs), whose coordinates exceed the range where floor(p * inv) is an exact f32 integer
 // below 2^23, or that is larger than the list limits falls through to the general path untouched (counters[4]).
-template <int NT>
-__device__ __forceinline__ void bitonic_sort_pairs(unsigned* hi, unsigned short* lo, int n, int tid) {
-  auto cx = [&](int i, int l) {
-    const unsigned hi_i = hi[i], hi_l = hi[l];
-    const unsigned short lo_i = lo[i], lo_l = lo[l];
-    if (hi_i > hi_l || (hi_i == hi_l && lo_i > lo_l)) { hi[i] = hi_l; hi[l] = hi_i; lo[i] = lo_l; lo[l] = lo_i; }
+// Stable LSD radix sort of n (voxel index, first point) pairs by the voxel index, 7 bits per pass.  The runs were generated in
+// input order, so a STABLE sort on the voxel index alone leaves the runs of one voxel in ascending point order — the order the
+// sums need.  Every thread keeps its CAPR / NT elements in registers (wave w owns the contiguous stretch [w * EPT * 64, ...),
+// element = row k, lane l, so rows are 64 consecutive elements); the two LDS arrays are only the scatter target of a pass and
+// are read back in the same striped layout for the next one: one buffer instead of a ping-pong pair.  Per pass: per-(digit, wave)
+// counts from wave-level digit matching (7 ballots), one exclusive scan in digit-major order, scatter with the rank among the
+// equal digits of the row.  A bitonic network on the same keys took 385 us for 23 k runs (120 barrier-separated LDS stages);
+// three radix passes take a fraction of that.
+template <int NT, int CAPR>
+__device__ __forceinline__ void radix_sort_pairs(unsigned* hi, unsigned short* lo, unsigned short* cntw, int* s_w, int n, int key_bits, int tid) {
+  constexpr int NW = NT / 64, EPT = CAPR / NT, RB = 7, NB = 1 << RB, PER = NB * NW / NT;
+  static_assert(NB * NW % NT == 0 && PER == 2, "two counters per thread in the scan");
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int wbase = wave * EPT * 64;
+  const int rows = __builtin_amdgcn_readfirstlane(n > wbase ? min(EPT, (n - wbase + 63) >> 6) : 0);   // rows of this wave that hold anything (wave-uniform: scalar branches)
+  unsigned rv[EPT], rf[EPT];
+  auto load = [&]() {
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int p = wbase + k * 64 + lane;
+      const bool valid = k < rows && p < n;
+      rv[k] = valid ? hi[p] : 0xffffffffu;                                   // the tail of the last row sorts behind everything
+      rf[k] = valid ? (unsigned)lo[p] : 0u;
+    }
   };
-  const int npad = pow2ceil(n);
-  for (int k = 2; k <= npad; k <<= 1) {
-    const int hk = k >> 1;
-    for (int t = tid; t < (npad >> 1); t += NT) {                           // flip stage: i <-> block_end - i (all-ascending network:
-      const int base = (t / hk) * k, off = t & (hk - 1);                     // the slots n .. npad-1 stay imaginary +inf)
-      const int i = base + off, l = base + (k - 1 - off);
-      if (l < n) cx(i, l);
+  auto match = [&](unsigned d) {                                             // lanes of this wave holding the same digit
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < RB; ++bit) { const bool one = (d >> bit) & 1u; const unsigned long long bal = __ballot(one); m &= one ? bal : ~bal; }
+    return m;
+  };
+  load();
+  __syncthreads();                                                           // every element sits in a register: the LDS arrays are free
+  for (int shift = 0; shift < key_bits; shift += RB) {
+    for (int c = tid; c < NB * NW; c += NT) cntw[c] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (k < rows) {
+        const unsigned d = (rv[k] >> shift) & (NB - 1);
+        const unsigned long long m = match(d);
+        if ((m & lt) == 0ull) cntw[d * NW + wave] = (unsigned short)(cntw[d * NW + wave] + __popcll(m));   // the lowest lane of every group
+      }
+      __builtin_amdgcn_sched_barrier(0);                                     // one row at a time: interleaving the rows costs hundreds of registers
     }
     __syncthreads();
-    for (int j = k >> 2; j > 0; j >>= 1) {
-      for (int t = tid; t < (npad >> 1); t += NT) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        if (i + j < n) cx(i, i + j);
-      }
+    {                                                                        // exclusive scan of the NB * NW counts, digit-major
+      const int v0 = cntw[tid * 2], v1 = cntw[tid * 2 + 1], sum = v0 + v1;
+      const int inc = wave_scan_i32<false>(sum);
+      if (lane == 63) s_w[wave] = inc;
       __syncthreads();
+      int off = 0;
+#pragma unroll 1
+      for (int w = 0; w < wave; ++w) off += s_w[w];
+      const int base = off + inc - sum;
+      cntw[tid * 2] = (unsigned short)base;
+      cntw[tid * 2 + 1] = (unsigned short)(base + v0);
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (k < rows) {
+        unsigned key = rv[k];
+        asm volatile("" : "+v"(key));                                        // (keeps the compiler from carrying the histogram loop's 14 bit tests per row over in registers)
+        const unsigned d = (key >> shift) & (NB - 1);
+        const unsigned long long m = match(d);
+        const int base = cntw[d * NW + wave], pos = base + __popcll(m & lt);
+        hi[pos] = rv[k];
+        lo[pos] = (unsigned short)rf[k];
+        if ((m & lt) == 0ull) cntw[d * NW + wave] = (unsigned short)(base + __popcll(m));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (shift + RB < key_bits) { load(); __syncthreads(); }
   }
 }
 
+#ifdef ALOAM_VOX_TIMING   // variant builds (tools/build_variant.sh): block 0 prints the time of every phase of its first segment
+#define VOX_T(name) do { __syncthreads(); if (blockIdx.x == 0 && tid == 0 && li == blockIdx.x) { const long long t_ = wall_clock64(); printf("k_vox_lds %d n %d phase %d : %d x10ns\n", NT, n, __LINE__, (int)(t_ - t_prev)); t_prev = t_; } } while (0)
+#else
+#define VOX_T(name) do { } while (0)
+#endif
 template <int NT, int CAPR, int CAPN>
 __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
   constexpr int NW = NT / 64, ITS = CAPR / NT, U = 4;
@@ -641,7 +701,8 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
   unsigned* khi = reinterpret_cast<unsigned*>(vl_smem);                      // [CAPR] voxel index of a run
   unsigned short* klo = reinterpret_cast<unsigned short*>(khi + CAPR);       // [CAPR] first point of the run
   unsigned* cont = reinterpret_cast<unsigned*>(klo + CAPR);                  // [CAPN / 32] bit i: point i continues the run of i - 1
-  int* s_tab = reinterpret_cast<int*>(cont + CAPN / 32);                     // [ITS * NW + 1] voxel heads per (round, wave) -> offsets
+  unsigned short* cntw = reinterpret_cast<unsigned short*>(cont + CAPN / 32); // [128 * NW] radix counters of the sort
+  int* s_tab = reinterpret_cast<int*>(cntw + 128 * NW);                      // [ITS * NW + 1] voxel heads per (round, wave) -> offsets
   int* s_i = s_tab + ITS * NW + 1;                                           // [48] per-wave run counts / flags
   float* s_f = reinterpret_cast<float*>(s_i + 48);                           // [6][NW] bounding-box partials
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -657,6 +718,9 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
     const float inv = 1.0f / sg.leaf;
     const int chunk = ((n + NW - 1) / NW + 63) & ~63;                        // every wave owns a contiguous, 64-aligned stretch of the segment
     const int w0 = wave * chunk, w1 = min(n, w0 + chunk);
+#ifdef ALOAM_VOX_TIMING
+    long long t_prev = wall_clock64();
+#endif
     // ---- pass 1: bounding box, run heads ------------------------------------------------------------------------------------
     float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
     int heads = 0;
@@ -706,6 +770,7 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
 #pragma unroll 1
       for (int w = 1; w < NW; ++w) { gmn[q] = fminf(gmn[q], s_f[q * NW + w]); gmx[q] = fmaxf(gmx[q], s_f[(3 + q) * NW + w]); }
     }
+    VOX_T("pass1");
     int n_runs = 0, rank = 0;
     bool unfit = false;
 #pragma unroll 1
@@ -751,7 +816,13 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
         }
       }
       __syncthreads();
-      bitonic_sort_pairs<NT>(khi, klo, n_runs, tid);
+      VOX_T("pass2");
+      {
+        const long long cells = (long long)divb[0] * divb[1] * divb[2];      // every voxel index is below this (<= 2^31 - 1)
+        const int key_bits = cells > 1 ? 64 - __clzll(cells - 1) : 1;
+        radix_sort_pairs<NT, CAPR>(khi, klo, cntw, s_i + 32, n_runs, key_bits, tid);
+      }
+      VOX_T("sort");
       // ---- voxel heads among the sorted runs -> output rank ---------------------------------------------------------------------
       const int rounds = (n_runs + NT - 1) / NT;                             // rounds of NT sorted runs that hold any
       for (int it = 0; it < rounds; ++it) {
@@ -775,6 +846,7 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
       }
       __syncthreads();
       n_vox = s_tab[ITS * NW];
+      VOX_T("heads");
       // ---- centroids: the members of a voxel in input order (runs ascending, points of a run consecutive) ----------------------
 #pragma unroll 1
       for (int it = 0; it < rounds; ++it) {
@@ -785,24 +857,37 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
         const unsigned vi = khi[p];
         float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
         int cnt = 0;
-        for (int q = p; q < n_runs && khi[q] == vi; ++q) {
-          int e = klo[q];
-          // length of the run: the continuation bits that follow its first point
-          int len = 1;
-          while (e + len < n && ((cont[(e + len) >> 5] >> ((e + len) & 31)) & 1u)) ++len;
-          for (int o = 0; o < len; o += 4) {                                 // four independent loads, added in order
-            float4 pt[4];
+        // the members in order: runs q = p, p + 1, ... of this voxel, the points of a run while the continuation bit is set.  Up to
+        // eight member indices are collected from LDS first, their loads issued together, then added in order: one memory round trip
+        // per eight members instead of one per run.
+        int q = p, e = klo[p];
+        bool have = true;
+        while (have) {
+          int idx[8], m = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) pt[k] = in[e + (o + k < len ? o + k : o)];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (o + k < len) { sx += pt[k].x; sy += pt[k].y; sz += pt[k].z; si += pt[k].w; }
+          for (int k = 0; k < 8; ++k) {
+            idx[k] = e;
+            if (have) {
+              ++m;
+              if (e + 1 < n && ((cont[(e + 1) >> 5] >> ((e + 1) & 31)) & 1u)) ++e;
+              else { ++q; if (q < n_runs && khi[q] == vi) e = klo[q]; else have = false; }
+            }
           }
-          cnt += len;
+          float4 pt[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) pt[k] = in[idx[k]];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) if (k < m) { sx += pt[k].x; sy += pt[k].y; sz += pt[k].z; si += pt[k].w; }
+          cnt += m;
         }
         const float fc = (float)cnt;
         stage[s_tab[it * NW + wave] + vrank] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
       }
     }
+    VOX_T("sums");
+#ifdef ALOAM_VOX_TIMING
+    if (blockIdx.x == 0 && tid == 0 && li == blockIdx.x) printf("k_vox_lds<%d> n %d runs %d voxels %d\n", NT, n, n_runs, n_vox);
+#endif
     if (sg.final_out) {                                                      // in-place filter: back over the cube once every member has been read
       __syncthreads();
       if (stage != sg.final_out && !(dx * dy * dz > 2147483647ll)) for (int i = tid; i < n_vox; i += NT) sg.final_out[i] = stage[i];
@@ -865,6 +950,71 @@ __global__ __launch_bounds__(256) void k_mapgrid_fill(MapArgs a) {
     const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
     const int pos = atomicAdd(&cur[hash_cell((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv)) & (H - 1)], 1);
     sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(g));
+  }
+}
+
+// The same structure built by ONE 1024-thread workgroup per (sequence, class) with an LDS counting sort (count -> scan -> fill),
+// the way k_build_grids builds the odometry grids: no global atomics, no zero-fill of the count table, one launch instead of
+// memset + three.  Used whenever the bucket table fits the LDS (H <= 16384, i.e. pools up to 256 k points per class).
+__global__ __launch_bounds__(1024) void k_mapgrid_build(MapArgs a) {
+  const int b = blockIdx.x, cls = blockIdx.y, tid = threadIdx.x;
+  const MapSeq& ms = a.seq[b];
+  const int n = ms.from_total[cls], nv = ms.n_valid, H = a.grid_H[cls];
+  const int* tab = a.tab + (long long)b * kTabInts;
+  extern __shared__ __attribute__((aligned(16))) int mg_lds[];
+  int* cnt = mg_lds;                       // [H]
+  int* part = cnt + H;                     // [1024]
+  int* s_pref = part + 1024;               // [80] start of every valid cube in the concatenated submap
+  int* s_off = s_pref + 80;                // [80] its offset in the class pool
+  int* start = a.grid_start[cls] + (long long)b * (H + 1);
+  float4* sorted = a.grid_sorted[cls] + (long long)b * a.pool_cap;
+  const float4* pool = a.pool[cls] + (long long)b * a.pool_cap;
+  for (int h = tid; h < H; h += 1024) cnt[h] = 0;
+  if (tid <= nv) s_pref[tid] = tab[80 + cls * 80 + tid];
+  if (tid < nv) s_off[tid] = cube_table(a, b, cls)[tab[tid]].off;
+  __syncthreads();
+  constexpr int U = 4;
+  auto fetch = [&](int base, float4* p) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int g = base + u * 1024 + tid;
+      g = g < n ? g : n - 1;
+      int lo = 0, hi = nv - 1;
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= g) lo = mid; else hi = mid - 1; }
+      p[u] = pool[s_off[lo] + (g - s_pref[lo])];
+    }
+  };
+  auto bucket = [&](const float4& p) { return (int)(hash_cell((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv)) & (unsigned)(H - 1)); };
+  for (int base = 0; base < n; base += U * 1024) {
+    float4 p[U];
+    fetch(base, p);
+#pragma unroll
+    for (int u = 0; u < U; ++u) if (base + u * 1024 + tid < n) atomicAdd(&cnt[bucket(p[u])], 1);
+  }
+  __syncthreads();
+  const int per = H / 1024;
+  int local = 0;
+  for (int k = 0; k < per; ++k) local += cnt[tid * per + k];
+  part[tid] = local;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int x = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += x;
+    __syncthreads();
+  }
+  int run = part[tid] - local;
+  for (int k = 0; k < per; ++k) { const int c = cnt[tid * per + k]; cnt[tid * per + k] = run; start[tid * per + k] = run; run += c; }
+  if (tid == 1023) start[H] = run;
+  __syncthreads();
+  for (int base = 0; base < n; base += U * 1024) {
+    float4 p[U];
+    fetch(base, p);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int g = base + u * 1024 + tid;
+      if (g < n) { const int pos = atomicAdd(&cnt[bucket(p[u])], 1); sorted[pos] = make_float4(p[u].x, p[u].y, p[u].z, __int_as_float(g)); }
+    }
   }
 }
 
@@ -1404,8 +1554,9 @@ void launch_map_stack_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s
 void launch_map_cube_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s) {
   hipLaunchKernelGGL(k_map_cube_segments, dim3((a.B * 2 * kMapValidMax + 255) / 256), dim3(256), 0, s, a, v);
 }
-constexpr int kVoxSmallRuns = 8192, kVoxBigRuns = 20480;
-constexpr size_t vox_lds_bytes(int nt, int capr, int capn) { return (size_t)capr * 6 + (size_t)capn / 8 + sizeof(int) * ((size_t)(capr / nt) * (nt / 64) + 1 + 48) + sizeof(float) * 6 * (nt / 64) + 64; }
+constexpr int kVoxSmallRuns = 8192, kVoxBigRuns = 24576;
+constexpr size_t vox_lds_bytes(int nt, int capr, int capn) { return (size_t)capr * 6 + (size_t)capn / 8 + 2 * 128 * (size_t)(nt / 64) + sizeof(int) * ((size_t)(capr / nt) * (nt / 64) + 1 + 48) + sizeof(float) * 6 * (nt / 64) + 64; }
+static_assert(vox_lds_bytes(1024, kVoxBigRuns, kVoxBigN) <= 163840, "one workgroup may use the whole 160 KiB of a CU, not more");
 int prepare_voxel_filter() {     // the 1024-thread instance needs > 64 KiB of dynamic LDS (attribute of the function on the current device)
   return hipFuncSetAttribute((const void*)k_vox_lds<1024, kVoxBigRuns, kVoxBigN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)vox_lds_bytes(1024, kVoxBigRuns, kVoxBigN)) == hipSuccess ? 0 : -1;
@@ -1415,6 +1566,7 @@ void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
   const int nsmall = v.n_segs < 4096 ? v.n_segs : 4096, nbig = v.n_segs < 1024 ? v.n_segs : 1024;
   hipLaunchKernelGGL((k_vox_lds<1024, kVoxBigRuns, kVoxBigN>), dim3(nbig), dim3(1024), vox_lds_bytes(1024, kVoxBigRuns, kVoxBigN), s, v, 1);
   hipLaunchKernelGGL((k_vox_lds<256, kVoxSmallRuns, kVoxSmallN>), dim3(nsmall), dim3(256), vox_lds_bytes(256, kVoxSmallRuns, kVoxSmallN), s, v, 0);
+  hipLaunchKernelGGL((k_vox_lds<64, kVoxTinyN, kVoxTinyN>), dim3(v.n_segs < 16384 ? v.n_segs : 16384), dim3(64), vox_lds_bytes(64, kVoxTinyN, kVoxTinyN), s, v, 2);
   // ... then the general path for whatever did not fit: every kernel returns at once when counters[4] == 0 (no tiles)
   if (tile_bound > 1024) tile_bound = 1024;            // the kernels stride over the device-side tile list
   hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(1024), 0, s, v);
@@ -1426,7 +1578,16 @@ void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
   hipLaunchKernelGGL(k_vox_emit, dim3(tile_bound), dim3(256), 0, s, v);
   hipLaunchKernelGGL(k_vox_copyback, dim3(tile_bound), dim3(256), 0, s, v);
 }
+static size_t mapgrid_lds_bytes(int H) { return sizeof(int) * ((size_t)H + 1024 + 160); }
+int prepare_map_grid(int H) {
+  if (H > 16384) return 0;                 // larger tables use the global counting sort
+  return hipFuncSetAttribute((const void*)k_mapgrid_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mapgrid_lds_bytes(H)) == hipSuccess ? 0 : -1;
+}
 void launch_map_grid(const MapArgs& a, hipStream_t s) {
+  if (a.grid_H[0] <= 16384 && a.grid_H[1] <= 16384 && a.grid_H[0] == a.grid_H[1]) {
+    hipLaunchKernelGGL(k_mapgrid_build, dim3(a.B, 2), dim3(1024), mapgrid_lds_bytes(a.grid_H[0]), s, a);
+    return;
+  }
   for (int cls = 0; cls < 2; ++cls) (void)hipMemsetAsync(a.grid_cnt[cls], 0, sizeof(int) * (size_t)a.B * a.grid_H[cls], s);
   const dim3 g(32, a.B, 2);                              // grid-stride over the submap of each (sequence, class)
   hipLaunchKernelGGL(k_mapgrid_count, g, dim3(256), 0, s, a);

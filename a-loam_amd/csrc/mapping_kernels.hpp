@@ -7,7 +7,7 @@ namespace aloam {
 constexpr int kMapW = 21, kMapH = 21, kMapD = 11, kMapCubes = kMapW * kMapH * kMapD;   // reference src/laserMapping.cpp:75-80
 constexpr int kMapValidMax = 75;                                                       // 5 x 5 x 3 window (:512-529)
 constexpr int kVoxTile = 2048;                                                         // keys per sort tile (general path)
-constexpr int kVoxSmallN = 8192, kVoxBigN = 65536;                                    // segment sizes the single-workgroup LDS filter takes (256 / 1024 threads)
+constexpr int kVoxTinyN = 2048, kVoxSmallN = 8192, kVoxBigN = 65536;                                    // segment sizes the single-workgroup LDS filter takes (256 / 1024 threads)
 
 enum MapErrBits { kMapErrPool = 1, kMapErrKeys = 2, kMapErrSegment = 4 };
 
@@ -54,8 +54,8 @@ struct VoxArgs {
   int* tile_heads;         // [tile_cap]
   int* tile_pref;          // [tile_cap + 1]
   int* counters;           // [0] total tiles, [1] error of this step, [2] merge levels needed, [3] earlier steps with an error,
-                           // [4] segments left to the general path, [5] / [6] lengths of the two LDS-filter lists
-  int* lists;              // [2][n_segs] segment ids for k_vox_lds (small, big)
+                           // [4] segments left to the general path, [5] / [6] / [7] lengths of the three LDS-filter lists
+  int* lists;              // [3][n_segs] segment ids for k_vox_lds (small, big, tiny)
   unsigned long long* keys[2];
   float4* tmp;             // [key_cap]
   int* bbox;               // [n_segs][6] order-preserving ints
@@ -101,6 +101,7 @@ void launch_map_stack_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s
 void launch_map_cube_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s);
 void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s);
 int prepare_voxel_filter();
+int prepare_map_grid(int H);
 void launch_map_grid(const MapArgs& a, hipStream_t s);
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s);
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s);
