@@ -264,3 +264,14 @@ int orc_knn_search(const float* target_xyzi, int n_target, const float* query_xy
 void orc_sym_eigen3(const double A[9], double vals[3], double vecs[9]) { orc::sym_eigen3(A, vals, vecs); }
 void orc_lstsq_5x3(const double A[15], const double b[5], double x[3]) { orc::lstsq_5x3(A, b, x); }
 }
+
+// ---- decision log (thread-local; see oracle_internal.hpp) ----------------------------------------------------------------------
+namespace orc { thread_local std::vector<Decision>* g_decision_log = nullptr; }
+static thread_local std::vector<orc::Decision> t_decisions;
+extern "C" void orc_decision_log(int enable) { t_decisions.clear(); orc::g_decision_log = enable ? &t_decisions : nullptr; }
+extern "C" long long orc_decision_log_size(void) { return (long long)t_decisions.size(); }
+extern "C" long long orc_decision_log_fetch(int* kinds, double* values, double* thresholds, long long cap) {
+  const long long n = (long long)t_decisions.size() < cap ? (long long)t_decisions.size() : cap;
+  for (long long i = 0; i < n; ++i) { kinds[i] = t_decisions[i].kind; values[i] = t_decisions[i].value; thresholds[i] = t_decisions[i].threshold; }
+  return (long long)t_decisions.size();
+}

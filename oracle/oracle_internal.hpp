@@ -92,6 +92,21 @@ struct MapState {
   LmSummary lm[2];
   MapState() : corner(NUM), surf(NUM) {}
 };
+// ---- decision log (tests/test_decision_margins.py): when enabled, every threshold decision of the path records the quantity it
+// compared and the threshold, so that a test can ask how far the data sits from the points where a last-bit difference of a
+// third-party routine (Eigen's eigen-solver / QR, FLANN's distance sum) or of the device arithmetic could flip a decision.
+enum DecisionKind { kDecCurvCorner = 0,   // cloudCurvature > 0.1      (reference src/scanRegistration.cpp:296)
+                    kDecCurvFlat = 1,     // cloudCurvature < 0.1      (:351)
+                    kDecGap = 2,          // neighbour step^2 > 0.05   (:324,:336,:371,:383)
+                    kDecRange = 3,        // x^2+y^2+z^2 < minimum_range^2 (:99)
+                    kDecOdomNN = 4,       // pointSearchSqDis[0] < DISTANCE_SQ_THRESHOLD = 25 (reference src/laserOdometry.cpp:305,393)
+                    kDecMapKnn = 5,       // pointSearchSqDis[4] < 1.0 (reference src/laserMapping.cpp:582,650)
+                    kDecEigRatio = 6,     // saes.eigenvalues()[2] > 3 * saes.eigenvalues()[1] (:611)
+                    kDecPlaneFit = 7 };   // fabs(norm . p + negative_OA_dot_norm) > 0.2 (:672-681)
+struct Decision { int kind; double value, threshold; };
+extern thread_local std::vector<Decision>* g_decision_log;
+inline void log_decision(int kind, double value, double threshold) { if (g_decision_log) g_decision_log->push_back(Decision{kind, value, threshold}); }
+
 int mapping_step(const orc_config& cfg, MapState* st, const double q_wodom[4], const double t_wodom[3], const std::vector<P4>& corner_last,
                  const std::vector<P4>& surf_last, const std::vector<P4>& full_res);
 void sym_eigen3(const double A[9], double vals[3], double vecs[9]);           // SelfAdjointEigenSolver<Matrix3d> stand-in (ascending)

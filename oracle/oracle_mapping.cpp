@@ -160,6 +160,7 @@ int mapping_step(const orc_config& cfg, MapState* st, const double q_wodom[4], c
         const P4 ori = st->corner_stack[i];
         const P4 sel = associate_to_map(ori, par);
         const int n = tree_corner.query(sel, 5, cfg.nn_brute != 0, idx, d2);
+        if (n >= 5) log_decision(kDecMapKnn, d2[4], 1.0);
         if (n < 5 || !(d2[4] < 1.0)) continue;
         V3d near[5], center{0, 0, 0};
         for (int j = 0; j < 5; ++j) { near[j] = V3d{corner_from_map[idx[j]].x, corner_from_map[idx[j]].y, corner_from_map[idx[j]].z}; center = center + near[j]; }
@@ -172,6 +173,7 @@ int mapping_step(const orc_config& cfg, MapState* st, const double q_wodom[4], c
         }
         double vals[3], vecs[9];
         sym_eigen3(cov, vals, vecs);
+        log_decision(kDecEigRatio, vals[2], 3 * vals[1]);
         if (vals[2] > 3 * vals[1]) {                                                   // :611
           const V3d dir{vecs[0 * 3 + 2], vecs[1 * 3 + 2], vecs[2 * 3 + 2]};
           EdgeRec e;
@@ -186,6 +188,7 @@ int mapping_step(const orc_config& cfg, MapState* st, const double q_wodom[4], c
         const P4 ori = st->surf_stack[i];
         const P4 sel = associate_to_map(ori, par);
         const int n = tree_surf.query(sel, 5, cfg.nn_brute != 0, idx, d2);
+        if (n >= 5) log_decision(kDecMapKnn, d2[4], 1.0);
         if (n < 5 || !(d2[4] < 1.0)) continue;
         double A[15], B[5] = {-1, -1, -1, -1, -1}, x[3];
         for (int j = 0; j < 5; ++j) { A[j * 3 + 0] = surf_from_map[idx[j]].x; A[j * 3 + 1] = surf_from_map[idx[j]].y; A[j * 3 + 2] = surf_from_map[idx[j]].z; }
@@ -197,6 +200,7 @@ int mapping_step(const orc_config& cfg, MapState* st, const double q_wodom[4], c
         bool valid = true;
         for (int j = 0; j < 5; ++j) {
           const P4& p = surf_from_map[idx[j]];
+          log_decision(kDecPlaneFit, std::fabs(nrm.x * p.x + nrm.y * p.y + nrm.z * p.z + negative_OA_dot_norm), 0.2);
           if (std::fabs(nrm.x * p.x + nrm.y * p.y + nrm.z * p.z + negative_OA_dot_norm) > 0.2) { valid = false; break; }
         }
         if (valid) st->norms.push_back(NormRec{V3d{ori.x, ori.y, ori.z}, nrm, negative_OA_dot_norm, (int)i});

@@ -135,6 +135,7 @@ int odometry_step(const orc_config& cfg, const std::vector<P4>& sharp, const std
         int nn; float nnd;
         st->tree_corner.query(sel, cfg.nn_brute != 0, &nn, &nnd);
         int closest = -1, min2 = -1;
+        log_decision(kDecOdomNN, nnd, DISTANCE_SQ_THRESHOLD);
         if (nnd < DISTANCE_SQ_THRESHOLD) {
           closest = nn;
           const int cid = (int)CL[closest].i;
@@ -168,6 +169,7 @@ int odometry_step(const orc_config& cfg, const std::vector<P4>& sharp, const std
         int nn; float nnd;
         st->tree_surf.query(sel, cfg.nn_brute != 0, &nn, &nnd);
         int closest = -1, min2 = -1, min3 = -1;
+        log_decision(kDecOdomNN, nnd, DISTANCE_SQ_THRESHOLD);
         if (nnd < DISTANCE_SQ_THRESHOLD) {
           closest = nn;
           const int cid = (int)SL[closest].i;

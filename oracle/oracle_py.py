@@ -84,6 +84,9 @@ def lib():
         L.orc_knn_search.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]
         L.orc_sym_eigen3.argtypes = [vp, vp, vp]; L.orc_sym_eigen3.restype = None
         L.orc_lstsq_5x3.argtypes = [vp, vp, vp]; L.orc_lstsq_5x3.restype = None
+        L.orc_decision_log.argtypes = [C.c_int]; L.orc_decision_log.restype = None
+        L.orc_decision_log_size.argtypes = []; L.orc_decision_log_size.restype = C.c_longlong
+        L.orc_decision_log_fetch.argtypes = [vp, vp, vp, C.c_longlong]; L.orc_decision_log_fetch.restype = C.c_longlong
         _lib = L
     return _lib
 
@@ -313,3 +316,20 @@ def quat_plus(q, delta):
 
 for _name, _fn in _map_methods().items():
     setattr(Oracle, _name, _fn)
+
+
+DECISION_KINDS = ("curvature > 0.1", "curvature < 0.1", "gap^2 > 0.05", "range^2 < min_range^2", "odometry d2 < 25", "map 5th neighbour d2 < 1",
+                  "eigenvalue ratio > 3", "plane residual > 0.2")
+
+
+def decision_log(enable=True):
+    """Start (and clear) or stop the calling thread's decision log."""
+    lib().orc_decision_log(int(enable))
+
+
+def decisions():
+    """(kinds int32[n], values float64[n], thresholds float64[n]) recorded since decision_log(True)."""
+    n = lib().orc_decision_log_size()
+    k = np.zeros(n, np.int32); v = np.zeros(n); t = np.zeros(n)
+    lib().orc_decision_log_fetch(_p(k), _p(v), _p(t), n)
+    return k, v, t

@@ -165,6 +165,7 @@ int register_scan(const orc_config& cfg, const void* pts, int n_in, int stride_b
     P4 p;
     std::memcpy(&p, (const char*)pts + (size_t)n * stride_bytes, 16);
     if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;
+    log_decision(kDecRange, p.x * p.x + p.y * p.y + p.z * p.z, thres * thres);
     if (p.x * p.x + p.y * p.y + p.z * p.z < thres * thres) continue;
     in.push_back(p);
   }
@@ -257,8 +258,8 @@ int register_scan(const orc_config& cfg, const void* pts, int n_in, int stride_b
   };
   auto suppress = [&](int ind) {    // (:317-342, :364-388)
     picked[ind] = 1;
-    for (int l = 1; l <= 5; ++l) { if (gap2(ind + l, ind + l - 1) > 0.05) break; picked[ind + l] = 1; }
-    for (int l = -1; l >= -5; --l) { if (gap2(ind + l, ind + l + 1) > 0.05) break; picked[ind + l] = 1; }
+    for (int l = 1; l <= 5; ++l) { log_decision(kDecGap, gap2(ind + l, ind + l - 1), 0.05); if (gap2(ind + l, ind + l - 1) > 0.05) break; picked[ind + l] = 1; }
+    for (int l = -1; l >= -5; --l) { log_decision(kDecGap, gap2(ind + l, ind + l + 1), 0.05); if (gap2(ind + l, ind + l + 1) > 0.05) break; picked[ind + l] = 1; }
   };
 
   out->sharp.clear(); out->less_sharp.clear(); out->flat.clear(); out->less_flat.clear();
@@ -277,6 +278,7 @@ int register_scan(const orc_config& cfg, const void* pts, int n_in, int stride_b
       int largestPickedNum = 0;                                     // :291-344
       for (int k = ep; k >= sp; --k) {
         const int ind = sortInd[k];
+        if (picked[ind] == 0) log_decision(kDecCurvCorner, curv[ind], 0.1);
         if (picked[ind] == 0 && curv[ind] > 0.1) {
           largestPickedNum++;
           if (largestPickedNum <= 2) { label[ind] = 2; out->sharp.push_back(c[ind]); out->less_sharp.push_back(c[ind]); }
@@ -288,6 +290,7 @@ int register_scan(const orc_config& cfg, const void* pts, int n_in, int stride_b
       int smallestPickedNum = 0;                                    // :346-390
       for (int k = sp; k <= ep; ++k) {
         const int ind = sortInd[k];
+        if (picked[ind] == 0) log_decision(kDecCurvFlat, curv[ind], 0.1);
         if (picked[ind] == 0 && curv[ind] < 0.1) {
           label[ind] = -1;
           out->flat.push_back(c[ind]);
