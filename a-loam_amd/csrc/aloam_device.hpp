@@ -88,7 +88,8 @@ struct OdomArgs {
   int* grid_start2[2];       // [B][H+1]
   float4* grid_sorted3c[2];  // coarse levels of the same two grids: they bound the search of far queries
   int* grid_start3c[2];      // [B][H+1]
-  int* grid_flags[2];        // [B][4]   flags[0] != 0: keys / coordinates out of range -> literal brute-force path; flags[1] != 0: not ring-sorted -> literal walks
+  int* grid_flags[2];        // [B][4]   flags[0] != 0: keys / coordinates out of range -> literal brute-force path; flags[1] != 0: not ring-sorted -> literal walks;
+                             //          flags[2] != 0: the coarse level holds 16-bit positions into the fine copy (k_build_grids_fused)
   int grid_H_corner, grid_H_surf;   // buckets (power of two, multiple of 1024)
   float4* sel_sharp;         // [B][R*12]  features moved to the start of the sweep with the current pose (k_transform_queries)
   float4* sel_flat;          // [B][R*24]

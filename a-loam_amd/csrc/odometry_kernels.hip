@@ -132,6 +132,136 @@ __device__ __forceinline__ unsigned hash3(int a, int b, int c) {
   return ((unsigned)a * 73856093u) ^ ((unsigned)b * 19349663u) ^ ((unsigned)c * 83492791u);
 }
 
+// ---- the same three grids of a cloud from TWO reads of it instead of six ---------------------------------------------------------
+// One 1024-thread workgroup per (sequence, cloud) keeps all three bucket tables in LDS at once — 16-bit counters, two to a word,
+// which is what makes 3 x 16384 buckets fit (96 KiB) — so the cloud is read once to count and once to fill, and the three
+// scattered 16-byte copies are written from the same registers.  16-bit offsets hold clouds of up to 65535 points (every synthetic
+// and KITTI-sized HDL-64 cloud); larger clouds (128-ring stress input) and tables above 16384 buckets keep the per-grid workgroups
+// of k_build_grids.  Traffic per point: 2 x 16 B read + 3 x 16 B written, against 6 x 16 + 3 x 16.
+#ifndef ALOAM_COARSE_VIA
+#define ALOAM_COARSE_VIA 0      // A/B builds: 1 = the coarse level of the fused build holds 16-bit positions into the fine copy instead of its
+                                // own 16-byte copy.  Measured on one box, same run: k_build_grids 1.42 -> 1.31 ms, k_associate[plane] 2.84 -> 3.25 ms
+#endif
+constexpr int kFusedMaxN = 65535, kFusedMaxH = 16384;
+__host__ __device__ __forceinline__ bool fused_takes(int n, int H) { return n <= kFusedMaxN && H <= kFusedMaxH; }
+
+__global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
+  constexpr int U = 4;
+  const int b = blockIdx.y, which = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const SeqMeta m = a.meta[b];
+  const int n = which == 0 ? m.n_corner_last : m.n_surf_last;
+  const float4* pts = which == 0 ? a.corner_last + (long long)b * a.R * 120 : a.surf_last + (long long)b * a.cap;
+  const GridView g = grid_view(a, b, which);
+  const int H = g.H;
+  if (!fused_takes(n, H)) return;
+  extern __shared__ __attribute__((aligned(16))) int lds[];
+  unsigned* tab = reinterpret_cast<unsigned*>(lds);     // [3][H / 2]: bucket h of table t lives in half (h & 1) of word t * H / 2 + h / 2
+  int* s_part = lds + 3 * (H / 2);                      // [3][16] wave totals of the scans
+  int* s_flag = s_part + 48;                            // bad, unsorted
+  int* const starts[3] = {g.start3, g.start3c, g.start2};
+  // ALOAM_COARSE_VIA builds only: the coarse level gets no 16-byte copy of its own, an entry is the 16-bit POSITION of the point in
+  // the fine copy (same buffer, read as unsigned short; flags[2] tells k_associate).  Both that and the ring grid as positions were
+  // measured and rejected: what the grid build saves in stores, the extra hop costs the association twice over.
+  unsigned short* const pos_list = reinterpret_cast<unsigned short*>(g.sorted3c);
+  if (n == 0) {
+    for (int t = 0; t < 3; ++t) for (int h = tid; h <= H; h += 1024) starts[t][h] = 0;
+    if (tid < 3) g.flags[tid] = tid == 2 ? ALOAM_COARSE_VIA : 0;
+    return;
+  }
+  for (int w = tid; w < 3 * (H / 2); w += 1024) tab[w] = 0u;
+  if (tid < 2) s_flag[tid] = 0;
+  __syncthreads();
+  const float inv0 = 1.0f / cell3_of(which), inv1 = 1.0f / (cell3_of(which) * kCell3CoarseFactor), inv2 = 1.0f / kCell2;
+  const unsigned hm = (unsigned)(H - 1);
+  auto buckets = [&](const float4& p, int key, unsigned* h) {
+    h[0] = hash3((int)floorf(p.x * inv0), (int)floorf(p.y * inv0), (int)floorf(p.z * inv0)) & hm;
+    h[1] = hash3((int)floorf(p.x * inv1), (int)floorf(p.y * inv1), (int)floorf(p.z * inv1)) & hm;
+    h[2] = hash3((int)floorf(p.x * inv2), (int)floorf(p.y * inv2), key) & hm;
+  };
+  auto fetch = [&](int base, float4* p) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int i = base + u * 1024 + tid; p[u] = pts[i < n ? i : n - 1]; }
+  };
+  // ---- count (+ the sanity / ring-sorted flags of the cloud)
+  {
+    int bad = 0, unsorted = 0;
+    for (int base = 0; base < n; base += U * 1024) {
+      float4 p[U];
+      float pw[U];
+      fetch(base, p);
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int i = base + u * 1024 + tid; pw[u] = pts[i < n ? (i > 0 ? i - 1 : 0) : n - 1].w; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (base + u * 1024 + tid >= n) continue;
+        const int key = (int)p[u].w;
+        if (key < 0 || key > a.R || !(fabsf(p[u].x) < 4096.f && fabsf(p[u].y) < 4096.f && fabsf(p[u].z) < 4096.f)) bad = 1;
+        if (key < (int)pw[u]) unsorted = 1;
+        unsigned h[3];
+        buckets(p[u], key, h);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) atomicAdd(&tab[t * (H / 2) + (h[t] >> 1)], 1u << ((h[t] & 1u) * 16));
+      }
+    }
+    if (bad) atomicOr(&s_flag[0], 1);
+    if (unsorted) atomicOr(&s_flag[1], 1);
+  }
+  __syncthreads();
+  if (tid < 3) g.flags[tid] = tid == 2 ? ALOAM_COARSE_VIA : s_flag[tid];
+  // ---- exclusive scans of the three tables: every thread owns H / 1024 consecutive buckets (= H / 2048 words) of each
+  {
+    const int wpt = H / 2048;                                              // words per thread and table (2 at H = 4096, 8 at 16384)
+    int local[3], inc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      local[t] = 0;
+      for (int k = 0; k < wpt; ++k) { const unsigned w = tab[t * (H / 2) + tid * wpt + k]; local[t] += (int)(w & 0xffffu) + (int)(w >> 16); }
+      inc[t] = wave_scan_i32<false>(local[t]);
+      if (lane == 63) s_part[t * 16 + wave] = inc[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      int run = inc[t] - local[t];
+#pragma unroll 1
+      for (int w = 0; w < wave; ++w) run += s_part[t * 16 + w];
+      int* st = starts[t] + tid * wpt * 2;
+      for (int k = 0; k < wpt; ++k) {
+        const unsigned w = tab[t * (H / 2) + tid * wpt + k];
+        const int c0 = (int)(w & 0xffffu), c1 = (int)(w >> 16);
+        st[2 * k] = run; st[2 * k + 1] = run + c0;
+        tab[t * (H / 2) + tid * wpt + k] = (unsigned)run | ((unsigned)(run + c0) << 16);   // running offsets (<= n <= 65535)
+        run += c0 + c1;
+      }
+      if (tid == 1023) starts[t][H] = run;
+    }
+  }
+  __syncthreads();
+  // ---- fill: the three copies of every point from one read
+  for (int base = 0; base < n; base += U * 1024) {
+    float4 p[U];
+    fetch(base, p);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * 1024 + tid;
+      if (i >= n) continue;
+      const int key = (int)p[u].w;
+      unsigned h[3];
+      buckets(p[u], key, h);
+      unsigned pos[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const unsigned sh = (h[t] & 1u) * 16;
+        pos[t] = (atomicAdd(&tab[t * (H / 2) + (h[t] >> 1)], 1u << sh) >> sh) & 0xffffu;
+      }
+      const float4 e = make_float4(p[u].x, p[u].y, p[u].z, __uint_as_float((unsigned)i | ((unsigned)(key + 1) << 20)));
+      g.sorted3[pos[0]] = e;
+      if (ALOAM_COARSE_VIA) pos_list[pos[1]] = (unsigned short)pos[0]; else g.sorted3c[pos[1]] = e;
+      g.sorted2[pos[2]] = e;
+    }
+  }
+}
+
 #ifndef ALOAM_BG_WAVES
 #define ALOAM_BG_WAVES 4      // waves per SIMD the register budget is sized for (A/B builds)
 #endif
@@ -151,6 +281,7 @@ __global__ __launch_bounds__(1024, ALOAM_BG_WAVES) void k_build_grids(OdomArgs a
   const int n = which == 0 ? m.n_corner_last : m.n_surf_last;
   const float4* pts = which == 0 ? a.corner_last + (long long)b * a.R * 120 : a.surf_last + (long long)b * a.cap;
   const GridView g = grid_view(a, b, which);
+  if (fused_takes(n, g.H)) return;        // k_build_grids_fused built this cloud's grids already
   extern __shared__ __attribute__((aligned(16))) int lds[];
   int* cnt = lds;                         // [H]
   int* part = lds + g.H;                  // [1024]
@@ -158,7 +289,7 @@ __global__ __launch_bounds__(1024, ALOAM_BG_WAVES) void k_build_grids(OdomArgs a
   if (tid < 2) s_flag[tid] = n >= (1 << 20) && tid == 0 ? 1 : 0;
   if (n == 0) {
     for (int pass = pass_lo; pass < pass_hi; ++pass) { int* st = pass == 0 ? g.start3 : pass == 1 ? g.start3c : g.start2; for (int h = tid; h <= g.H; h += 1024) st[h] = 0; }
-    if (tid < 2 && pass_lo == 0) g.flags[tid] = 0;
+    if (tid < 3 && pass_lo == 0) g.flags[tid] = 0;
     return;
   }
   // The loops below keep the loads of the next round in flight while the current one is binned: on this ISA a wait for
@@ -213,7 +344,7 @@ __global__ __launch_bounds__(1024, ALOAM_BG_WAVES) void k_build_grids(OdomArgs a
       if (unsorted) atomicOr(&s_flag[1], 1);
     }
     __syncthreads();
-    if (pass == 0 && tid < 2) g.flags[tid] = s_flag[tid];
+    if (pass == 0 && tid < 3) g.flags[tid] = tid == 2 ? 0 : s_flag[tid];
     // exclusive scan of cnt[H]: per-thread run of H/1024 consecutive buckets + scan of the 1024 partial sums
     const int per = g.H / 1024;
     int local = 0;
@@ -287,8 +418,11 @@ __device__ __forceinline__ void shell3d(int r, int c, int* dx, int* dy, int* dz)
 // 2 for the corner class (measured: a third row only costs there).
 template <int kSweep> struct Kept { float4 p[kSweep]; bool a[kSweep]; bool ok; };
 
+// `via`: the list holds 16-bit positions into `sorted` instead of the entries themselves (coarse level of k_build_grids_fused): one
+// more, L2-resident, hop per candidate in exchange for 14 bytes per point the grid build does not write.
 template <int kSweep, class F>
-__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f, Kept<kSweep>* keep = nullptr) {
+__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f, Kept<kSweep>* keep = nullptr,
+                                           const unsigned short* __restrict__ via = nullptr) {
   const int incl = wave_scan_i32<false>(cnt);
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
@@ -315,7 +449,8 @@ __device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, in
         carry = __builtin_amdgcn_readlane(own[u], 63);
         const int i = base + u * 64 + lane;
         const int os = __shfl(s0, own[u] - 1, 64), oe = __shfl(excl, own[u] - 1, 64);
-        p[u] = sorted[i < total ? os + (i - oe) : 0];
+        const int at = i < total ? os + (i - oe) : 0;
+        p[u] = sorted[via ? (int)via[at] : at];
       }
     }
 #pragma unroll
@@ -396,7 +531,8 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
             cnt = g.start3c[h + 1] - s0;
           }
         }
-        wave_sweep<kSweep>(g.sorted3c, s0, cnt, lane, row, visit);
+        if (ALOAM_COARSE_VIA && g.flags[2]) wave_sweep<kSweep>(g.sorted3, s0, cnt, lane, row, visit, nullptr, reinterpret_cast<const unsigned short*>(g.sorted3c));
+        else wave_sweep<kSweep>(g.sorted3c, s0, cnt, lane, row, visit);
       }
       best = wave_min_u64(mine.v);
       const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
@@ -758,12 +894,19 @@ void launch_advance(SeqMeta* meta, int B, hipStream_t s) { hipLaunchKernelGGL(k_
 
 // -------------------------------------------------------------------------------------------------------
 size_t build_grids_lds_bytes(int H, int R) { return sizeof(int) * ((size_t)H + 1024 + 2 * (R + 8) + 4); }
+static size_t build_grids_fused_lds_bytes(int H) { return sizeof(int) * (3 * (size_t)(H / 2) + 48 + 8); }
 // The surf grid needs > 64 KiB of dynamic LDS: the attribute belongs to the function ON the current device; aloam_create sets it
 // once per context (no process-global state).
 int prepare_build_grids(int H_surf) {
+  if (hipFuncSetAttribute((const void*)k_build_grids_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_grids_fused_lds_bytes(kFusedMaxH)) != hipSuccess) return -1;
   return hipFuncSetAttribute((const void*)k_build_grids, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_grids_lds_bytes(H_surf, kMaxRings)) == hipSuccess ? 0 : -1;
 }
 void launch_build_grids(const OdomArgs& a, hipStream_t s) {
+  // clouds of up to 65535 points: all three grids by one workgroup from two reads; the per-grid workgroups below return at once for those
+  // (always launched: which kernel owns a cloud is decided per cloud by fused_takes() in both kernels; LDS sized for the larger table
+  // that can be fused)
+  const int hc = a.grid_H_corner <= kFusedMaxH ? a.grid_H_corner : 0, hs = a.grid_H_surf <= kFusedMaxH ? a.grid_H_surf : 0;
+  if (hc || hs) hipLaunchKernelGGL(k_build_grids_fused, dim3(2, a.B), dim3(1024), build_grids_fused_lds_bytes(hc > hs ? hc : hs), s, a);
   hipLaunchKernelGGL(k_build_grids, dim3(ALOAM_BG_SPLIT ? 6 : 2, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
 }
 void launch_transform_queries(const OdomArgs& a, hipStream_t s) {

@@ -491,3 +491,18 @@ def test_two_rank_bench_run(binding, tmp_path):
         with open(os.path.join(out_dir, "two_rank_shared_gpu.json"), "w") as f:
             json.dump({"how": "ALOAM_BENCH_SHARED_GPU=1 python bench.py --gpus 2 --batch 64 --steps 4 --warmup 2 --frames 3 --no-cpu-baseline --no-extras (two ranks sharing ONE MI355X, gloo control plane) next to --gpus 1 --batch 128",
                        "two_ranks": two, "one_rank": one}, f, indent=1)
+
+
+def test_ring_count_lookback_survives_concurrent_streams():
+    """k_ring_features workgroups wait for the counts of the rings in front of them (bounded spin, kErrInternal on time-out).  Four
+    contexts on four streams with mapping enabled interleave their launches on the device for 200 steps: the run must finish, and
+    aloam_synchronize (called by bench.py at the end of the timed region) must not report the time-out."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--batch", "128", "--contexts", "4", "--mapping", "--map-pool", "131072", "--steps", "200",
+                        "--warmup", "2", "--frames", "4", "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["steps"] == 200 and line["config"]["contexts_per_gpu"] == 4 and line["value"] > 1000
