@@ -301,8 +301,11 @@ def test_live_distortion_build_matches_oracle(O, sequence):
 @pytest.mark.parametrize("path", DISTORT_GOLDENS)
 def test_gpu_distortion_mode_vs_reference_code(binding, path):
     """aloam_config.distortion on the HIP path against the reference's own DISTORTION 1 build: poses within the north-star
-    tolerance, correspondence counts within a handful (the device evaluates slerp with its own acos / sin, so a transformed
-    query can round differently in its last f32 bit and flip a threshold decision)."""
+    tolerance.  Correspondence counts are compared within a handful only, for the same reason the shipped mode's test above
+    compares no counts at all: the reference sums the members of a less-flat voxel in the order its unstable std::sort leaves
+    them, the HIP path in input order (<= 4 ulp in those centroids), and a last-bit difference in a target
+    point can flip a near-tie.  Against the oracle in the same (canonical) order the correspondences are identical:
+    tests/test_gpu_parity.py::test_distortion_mode_matches_oracle."""
     g = np.load(path)
     gpu = binding.Aloam(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), max_points=40000, distortion=True)
     for k in range(_frames(g)):
