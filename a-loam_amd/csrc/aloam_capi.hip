@@ -78,6 +78,7 @@ struct aloam_ctx {
   float4* d_mgrid_sorted[2] = {nullptr, nullptr}; int* d_mgrid_start[2] = {nullptr, nullptr}; int* d_mgrid_cnt[2] = {nullptr, nullptr};
   MapEdgeRec* d_medges = nullptr; MapNormRec* d_mnorms = nullptr; float4* d_registered = nullptr; float4* d_knn = nullptr;
   int* d_vox_lists = nullptr;
+  int* d_rec_tiles = nullptr; int rec_tiles_corner = 0, rec_tiles_per_seq = 0;
   VoxSeg* d_segs = nullptr; int *d_tile_seg = nullptr, *d_tile_heads = nullptr, *d_tile_pref = nullptr, *d_vox_counters = nullptr, *d_bbox = nullptr;
   unsigned long long* d_keys[2] = {nullptr, nullptr}; float4* d_voxtmp = nullptr;
   bool system_inited = false;        // reference src/laserOdometry.cpp:69
@@ -359,7 +360,7 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
                   c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
-                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag, c->d_vox_lists};
+                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag, c->d_vox_lists, c->d_rec_tiles};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_nin) (void)hipHostFree(c->h_nin);
@@ -828,6 +829,7 @@ static MapArgs map_args(aloam_ctx* c) {
   a.edges = c->d_medges; a.norms = c->d_mnorms; a.knn = c->d_knn;
   a.lm_max_iterations = c->cfg.lm_max_iterations;
   a.vox_counters = c->d_vox_counters;
+  a.rec_tiles = c->d_rec_tiles; a.rec_tiles_per_seq = c->rec_tiles_per_seq; a.rec_tiles_corner = c->rec_tiles_corner;
   return a;
 }
 static VoxArgs vox_args(aloam_ctx* c, int n_segs, int levels) {
@@ -877,6 +879,9 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
     if ((rc = dmalloc(c, &c->d_mgrid_cnt[k], B * (size_t)c->map_H[k]))) return rc;
     if ((rc = dmalloc(c, &c->d_keys[k], (size_t)c->map_key_cap))) return rc;
   }
+  c->rec_tiles_corner = (int)((R * 120 + 255) / 256);
+  c->rec_tiles_per_seq = c->rec_tiles_corner + (int)((cap + 255) / 256);
+  if ((rc = dmalloc(c, &c->d_rec_tiles, B * (size_t)c->rec_tiles_per_seq))) return rc;
   if ((rc = dmalloc(c, &c->d_medges, B * R * 120))) return rc;
   if ((rc = dmalloc(c, &c->d_mnorms, B * cap))) return rc;
   if ((rc = dmalloc(c, &c->d_registered, B * cap))) return rc;

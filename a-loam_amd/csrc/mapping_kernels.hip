@@ -1241,13 +1241,21 @@ __global__ __launch_bounds__(256) void k_map_fit(MapArgs a) {
   const MapSeq& ms = a.seq[b];
   const int n = ms.n_stack[CLS];
   const long long sb = (long long)b * (CLS == 0 ? a.R * 120 : a.cap);
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const float4 ori = a.stack[CLS][sb + i];                               // pointOri (:578, :644)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_wcnt[4];
+  int* tile_cnt = a.rec_tiles + (long long)b * a.rec_tiles_per_seq + (CLS == 0 ? 0 : a.rec_tiles_corner);
+  // Only the valid factors are stored, compacted per tile of 256 consecutive stack points (record (tile, k) = the k-th valid
+  // point of the tile, in stack order; the number per tile in rec_tiles): k_map_solve then reads nothing but live records, densely.
+  // Corner points pass the line test a third of the time; their 80-byte records were re-streamed by every LM evaluation before.
+  for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+    const int i = i0 + tid;
+    const bool live = i < n;
+    const float4 ori = a.stack[CLS][sb + (live ? i : i0)];                 // pointOri (:578, :644)
     bool valid = false;
     double ra[3] = {0, 0, 0}, rb[3] = {0, 0, 0}, rd = 0.0;
     float nxs[5], nys[5], nzs[5];
     bool found = false;
-    if (ms.gate) {
+    if (ms.gate && live) {
       const float4* in = a.knn + ((long long)b * a.cap + i) * 4;
       const float4 q0 = in[0], q1 = in[1], q2 = in[2], q3 = in[3];
       found = q0.w != 0.f;
@@ -1294,21 +1302,30 @@ __global__ __launch_bounds__(256) void k_map_fit(MapArgs a) {
         if (ok) { valid = true; ra[0] = nx; ra[1] = ny; ra[2] = nz; rd = d; }
       }
     }
-    if (CLS == 0) {
-      MapEdgeRec e;
-      e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
+    const unsigned long long vm = __ballot(valid);
+    if (lane == 0) s_wcnt[wave] = __popcll(vm);
+    __syncthreads();
+    int rank = __popcll(vm & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rank += s_wcnt[w];
+    if (tid == 0) tile_cnt[i0 >> 8] = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if (valid) {
+      if (CLS == 0) {
+        MapEdgeRec e;
+        e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { e.a[k] = ra[k]; e.b[k] = rb[k]; }
-      e.valid = valid ? 1 : 0; e.pad = 0;
-      a.edges[(long long)b * a.R * 120 + i] = e;
-    } else {
-      MapNormRec e;
-      e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
+        for (int k = 0; k < 3; ++k) { e.a[k] = ra[k]; e.b[k] = rb[k]; }
+        e.valid = 1; e.pad = i;
+        a.edges[(long long)b * a.R * 120 + i0 + rank] = e;
+      } else {
+        MapNormRec e;
+        e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) e.n[k] = ra[k];
-      e.d = rd; e.valid = valid ? 1 : 0; e.pad = 0;
-      a.norms[(long long)b * a.cap + i] = e;
+        for (int k = 0; k < 3; ++k) e.n[k] = ra[k];
+        e.d = rd; e.valid = 1; e.pad = i;
+        a.norms[(long long)b * a.cap + i0 + rank] = e;
+      }
     }
+    __syncthreads();                                                       // s_wcnt is reused by the next tile
   }
 }
 
@@ -1320,7 +1337,7 @@ __global__ __launch_bounds__(256) void k_map_fit(MapArgs a) {
 #endif
 constexpr int kMapSolveThreads = ALOAM_MAP_SOLVE_THREADS;    // more waves do not pay: the kernel needs 256 VGPRs per lane for the f64 sums
 template <bool WITH_JAC>
-__device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const double t[3], double* acc, int* n_edge, int* n_norm) {
+__device__ void map_evaluate(const MapArgs& a, int b, const int* s_pref, const double q[4], const double t[3], double* acc, int* n_edge, int* n_norm) {
   const int tid = threadIdx.x;
   const MapSeq& ms = a.seq[b];
   const MapEdgeRec* E = a.edges + (long long)b * a.R * 120;
@@ -1357,13 +1374,22 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
     }
   };
   constexpr int U = 4;
-  const int n0 = ms.n_stack[0], n1 = ms.n_stack[1];
-  for (int i0 = tid; i0 < n0; i0 += U * kMapSolveThreads) {
+  // dense index d over the valid records -> tile by binary search in the tile prefixes (LDS, built once per launch), then the
+  // record at tile * 256 + (d - prefix[tile])
+  const int nt0 = (ms.n_stack[0] + 255) >> 8, nt1 = (ms.n_stack[1] + 255) >> 8;
+  const int* pre0 = s_pref, *pre1 = s_pref + nt0 + 1;
+  const int n0 = pre0[nt0], n1 = pre1[nt1];
+  auto locate = [](const int* pre, int nt, int d) {
+    int lo = 0, hi = nt - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (pre[mid] <= d) lo = mid; else hi = mid - 1; }
+    return (lo << 8) + (d - pre[lo]);
+  };
+  for (int d0 = tid; d0 < n0; d0 += U * kMapSolveThreads) {
     MapEdgeRec e[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int i = i0 + u * kMapSolveThreads; e[u] = E[i < n0 ? i : i0]; }
+    for (int u = 0; u < U; ++u) { const int d = d0 + u * kMapSolveThreads; e[u] = E[locate(pre0, nt0, d < n0 ? d : d0)]; }
 #pragma unroll
-    for (int u = 0; u < U; ++u) if (i0 + u * kMapSolveThreads < n0 && e[u].valid) edge_term(e[u]);
+    for (int u = 0; u < U; ++u) if (d0 + u * kMapSolveThreads < n0) edge_term(e[u]);
   }
   auto norm_term = [&](const MapNormRec& p) {
     ++np;
@@ -1380,12 +1406,12 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
       add_row(acc, J, r, rho1);
     }
   };
-  for (int i0 = tid; i0 < n1; i0 += U * kMapSolveThreads) {
+  for (int d0 = tid; d0 < n1; d0 += U * kMapSolveThreads) {
     MapNormRec pr[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { const int i = i0 + u * kMapSolveThreads; pr[u] = P[i < n1 ? i : i0]; }
+    for (int u = 0; u < U; ++u) { const int d = d0 + u * kMapSolveThreads; pr[u] = P[locate(pre1, nt1, d < n1 ? d : d0)]; }
 #pragma unroll
-    for (int u = 0; u < U; ++u) if (i0 + u * kMapSolveThreads < n1 && pr[u].valid) norm_term(pr[u]);
+    for (int u = 0; u < U; ++u) if (d0 + u * kMapSolveThreads < n1) norm_term(pr[u]);
   }
   *n_edge = ne;
   *n_norm = np;
@@ -1394,11 +1420,25 @@ __device__ void map_evaluate(const MapArgs& a, int b, const double q[4], const d
 __global__ __launch_bounds__(kMapSolveThreads) void k_map_solve(MapArgs a, int iter, int last) {
   const int b = blockIdx.x, tid = threadIdx.x;
   __shared__ double s_red[(kMapSolveThreads / 64) * 28];
+  extern __shared__ int s_pref[];                                            // exclusive prefixes of the valid records per tile: corner, then surf
   MapSeq& ms = a.seq[b];
+  {
+    const int nt0 = (ms.n_stack[0] + 255) >> 8, nt1 = (ms.n_stack[1] + 255) >> 8;
+    const int* tc = a.rec_tiles + (long long)b * a.rec_tiles_per_seq;
+    if (tid == 0) {                                                          // a few hundred tiles at most: one thread
+      int run = 0;
+      for (int k = 0; k < nt0; ++k) { s_pref[k] = run; run += ms.gate ? tc[k] : 0; }
+      s_pref[nt0] = run;
+      run = 0;
+      for (int k = 0; k < nt1; ++k) { s_pref[nt0 + 1 + k] = run; run += ms.gate ? tc[a.rec_tiles_corner + k] : 0; }
+      s_pref[nt0 + 1 + nt1] = run;
+    }
+    __syncthreads();
+  }
   double q[4] = {ms.par[0], ms.par[1], ms.par[2], ms.par[3]};
   double t[3] = {ms.par[4], ms.par[5], ms.par[6]};
   const LmResult lm = lm_solve_block<kMapSolveThreads / 64>([&](bool with_jac, const double* qq, const double* tt, double* acc, int* ne, int* np) {
-    if (with_jac) map_evaluate<true>(a, b, qq, tt, acc, ne, np); else map_evaluate<false>(a, b, qq, tt, acc, ne, np);
+    if (with_jac) map_evaluate<true>(a, b, s_pref, qq, tt, acc, ne, np); else map_evaluate<false>(a, b, s_pref, qq, tt, acc, ne, np);
   }, q, t, a.lm_max_iterations, s_red);
   if (tid == 0) {
     for (int k = 0; k < 4; ++k) ms.par[k] = q[k];
@@ -1603,7 +1643,9 @@ void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
   hipLaunchKernelGGL(k_map_search<1>, dim3(48, a.B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
-void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) { hipLaunchKernelGGL(k_map_solve, dim3(a.B), dim3(kMapSolveThreads), 0, s, a, iter, last ? 1 : 0); }
+void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) {
+  hipLaunchKernelGGL(k_map_solve, dim3(a.B), dim3(kMapSolveThreads), sizeof(int) * (size_t)(a.rec_tiles_per_seq + 2), s, a, iter, last ? 1 : 0);
+}
 void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s) {
   hipLaunchKernelGGL(k_map_cubeid, dim3(32, a.B, 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_map_compact_plan, dim3(a.B, 2), dim3(256), 0, s, a);

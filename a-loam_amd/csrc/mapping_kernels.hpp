@@ -33,7 +33,7 @@ struct alignas(16) MapSeq {                              // one per sequence
   int pad;
 };
 
-struct MapEdgeRec { double cp[3], a[3], b[3]; int valid, pad; };        // LidarEdgeFactor(curr_point, point_a, point_b, 1.0)      (:618)
+struct MapEdgeRec { double cp[3], a[3], b[3]; int valid, pad; };        // (pad: the stack index of the point)        // LidarEdgeFactor(curr_point, point_a, point_b, 1.0)      (:618)
 struct MapNormRec { double cp[3], n[3], d; int valid, pad; };          // LidarPlaneNormFactor(curr_point, norm, negative_OA_dot_norm) (:683)
 
 struct VoxSeg {                                          // one pcl::VoxelGrid::filter call
@@ -92,6 +92,8 @@ struct MapArgs {
   MapEdgeRec* edges;             // [B][R*120]
   MapNormRec* norms;             // [B][cap]
   int lm_max_iterations;
+  int* rec_tiles;                // [B][rec_tiles_per_seq] valid factor records per tile of 256 stack points: corner tiles, then surf tiles
+  int rec_tiles_per_seq, rec_tiles_corner;
   int* vox_counters;             // VoxArgs::counters: [1] capacity flag of this step's voxel filters, [3] earlier steps that raised it
 };
 constexpr int kTabInts = 256;   // [0..74] valid cube ids, [80..155] corner prefix, [160..235] surf prefix
