@@ -423,12 +423,98 @@ __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, i
   if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
 }
 
+// ---- stable radix sort of the 32-bit run keys of a ring on their voxel-index bits ------------------------------------------------
+// key = voxel index << EB | first element; the keys are generated in element order, so a STABLE sort on the voxel bits alone gives
+// the order the full-key sort gives.  8-bit digits, two or three passes (the voxel box of a ring has 2^14 .. 2^21 cells).  Every
+// thread keeps its keys in registers (wave w owns a contiguous, 64-aligned quarter of the keys; row k of a wave = 64 consecutive
+// keys), LDS is only the scatter target.  MEASURED AND NOT USED: against the LDS bitonic network it needs 9 instead of ~40 barriers
+// and about half the VALU instructions for the ~700 keys of a ring, yet k_ring_features as a whole ran 2.99 ms against 2.91 ms
+// (A/B on one box, two runs each, batch 1024): the sort is 7.5 us of the ~60 us a ring workgroup lives (device-timer build,
+// -DALOAM_RF_TIMING: curvature 10-15 us, reach 5, first-pass selection 20, redo + labels 1.5, voxel indices 3, run heads 2, sort
+// 7.5, voxel heads + gather 3, centroids 8), and the kernel is bound by the selection's VALU work.  Kept for A/B builds.
+#ifndef ALOAM_RF_RADIX
+#define ALOAM_RF_RADIX 0        // 1 = radix sort for the 32-bit run keys (k_vox_lds in the mapping stage uses the same scheme, where it pays)
+#endif
+template <int NPAD>
+__device__ __forceinline__ void radix_sort_run_keys(unsigned* keys, unsigned short* cntw, int* s_w, int n, int shift0, int key_bits, int tid) {
+  constexpr int NW = 4, RB = 8, NB = 1 << RB, EPT = NPAD / 256 + 1;
+  const int lane = tid & 63, wave = tid >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int chunk = (((n + NW - 1) / NW) + 63) & ~63;
+  const int w0 = wave * chunk, w1 = min(n, w0 + chunk);
+  const int rows = __builtin_amdgcn_readfirstlane(w1 > w0 ? (w1 - w0 + 63) >> 6 : 0);       // <= EPT, wave-uniform
+  unsigned rk[EPT];
+  auto load = [&]() {
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { const int p = w0 + k * 64 + lane; rk[k] = (k < rows && p < w1) ? keys[p] : 0xffffffffu; }
+  };
+  auto match = [&](unsigned d) {
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int bit = 0; bit < RB; ++bit) { const bool one = (d >> bit) & 1u; const unsigned long long bal = __ballot(one); m &= one ? bal : ~bal; }
+    return m;
+  };
+  load();
+  __syncthreads();
+  for (int shift = shift0; shift < shift0 + key_bits; shift += RB) {
+    for (int c = tid; c < NB * NW; c += 256) cntw[c] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (k < rows) {
+        const bool live = w0 + k * 64 + lane < w1;                           // the tail of a wave's last row takes no part
+        const unsigned d = (rk[k] >> shift) & (NB - 1);
+        const unsigned long long m = match(d) & __ballot(live);
+        if (live && (m & lt) == 0ull) cntw[d * NW + wave] = (unsigned short)(cntw[d * NW + wave] + __popcll(m));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    {                                                                        // exclusive scan of the NB * NW counts, digit-major: 4 per thread
+      int v[4], sum = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[q] = cntw[tid * 4 + q]; sum += v[q]; }
+      const int inc = wave_scan_i32<false>(sum);
+      if (lane == 63) s_w[wave] = inc;
+      __syncthreads();
+      int run = inc - sum;
+      for (int w = 0; w < wave; ++w) run += s_w[w];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { cntw[tid * 4 + q] = (unsigned short)run; run += v[q]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      if (k < rows) {
+        const bool live = w0 + k * 64 + lane < w1;
+        unsigned key = rk[k];
+        asm volatile("" : "+v"(key));                                        // (no carrying of the histogram loop's bit tests across the scan)
+        const unsigned d = (key >> shift) & (NB - 1);
+        const unsigned long long m = match(d) & __ballot(live);
+        if (live) {
+          const int base = cntw[d * NW + wave];
+          keys[base + __popcll(m & lt)] = key;
+          if ((m & lt) == 0ull) cntw[d * NW + wave] = (unsigned short)(base + __popcll(m));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (shift + RB < shift0 + key_bits) { load(); __syncthreads(); }
+  }
+}
+
+#ifdef ALOAM_RF_TIMING   // variant builds: one ring workgroup prints the duration of every phase (device timer, 10 ns units; each print itself costs ~130 us)
+#define RF_T(tag) do { __syncthreads(); if (blockIdx.x == 3 && blockIdx.y == 24 && threadIdx.x == 0) { const long long t_ = wall_clock64(); printf("k_ring_features phase %d : %d x10ns\n", tag, (int)(t_ - rf_t_prev)); rf_t_prev = wall_clock64(); } } while (0)
+#else
+#define RF_T(tag) do { } while (0)
+#endif
 // ---- second half of pcl::VoxelGrid for one ring: run heads -> sort of the run keys -> voxel heads ->
 // centroids in input order.  K = key type (voxel index << SHIFT | first element of the run), see the call site.
 template <int NPAD, typename K, int SHIFT>
 __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned char* flags, const signed char* label, int* s_scan, int* s_misc,
                                                const float4* cloud, float4* out, int L, int tid, int lane, int wave,
-                                               unsigned long long* lb_lf, int ring, int nrings, unsigned epoch, int* err) {
+                                               unsigned long long* lb_lf, int ring, int nrings, unsigned epoch, int* err, int key_bits, long long& rf_t_prev) {
   const unsigned* vis = reinterpret_cast<const unsigned*>(smem);               // region A: voxel index per element [NPAD] ...
   K* rkeys = reinterpret_cast<K*>(smem);                                      // ... replaced by the run keys once the heads are known
   constexpr unsigned kEMask = SHIFT >= 32 ? 0xffffffffu : ((1u << (SHIFT & 31)) - 1u);
@@ -473,8 +559,13 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
   for (int it = 0; it < EIT; ++it)
     if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = (K)(((K)myvi[it] << SHIFT) | (K)e); }   // vis is dead: every thread read its share before the barrier
   __syncthreads();
-  bitonic_sort_keys<K>(rkeys, n_runs, tid);
+  RF_T(6);   // run heads + keys
+  if (ALOAM_RF_RADIX && sizeof(K) == 4)     // region A behind the keys is free by now: radix counters there, wave totals in s_scan
+    radix_sort_run_keys<NPAD>(reinterpret_cast<unsigned*>(smem), reinterpret_cast<unsigned short*>(smem + 4 * NPAD), s_scan + 128, n_runs, SHIFT & 31, key_bits, tid);
+  else
+    bitonic_sort_keys<K>(rkeys, n_runs, tid);
 
+  RF_T(7);   // sort
   // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
   int n_vox = 0;
   unsigned vmask = 0;
@@ -510,6 +601,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
     if (lane == 0) { s_misc[40] = b0; s_misc[41] = b1; s_misc[42] = b2; s_misc[43] = b3; }
   }
   __syncthreads();
+  RF_T(8);   // voxel heads + gather of the counts in front
   out += s_misc[43];
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
@@ -532,6 +624,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
     const float fc = (float)cnt;
     out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
   }
+  RF_T(9);   // centroids
   return n_vox;
 }
 
@@ -549,6 +642,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     return;
   }
 
+  long long rf_t_prev = wall_clock64();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // region A (aliased over time): two 266-point xyz tiles during the curvature pass, then the curvature per point, then the voxel
   // index per element, then the run keys.  Keeping it at 8 * NPAD bytes is what lets seven workgroups share a CU's LDS.
@@ -628,6 +722,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     __syncthreads();
   }
 
+  RF_T(1);   // curvature
   // reach of the neighbour suppression around every point: a pick of i marks i+1 .. i+fw and i-1 .. i-bk (runs of consecutive
   // gap-free steps, at most 5).  Packed into the flag byte: bit1 gap, bits 2-4 fw, bits 5-7 bk.
   unsigned char rb[ITEMS];
@@ -651,12 +746,14 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   }
   __syncthreads();
 
+  RF_T(2);   // reach + curvature array
   // ---- corner / flat selection (:284-390): every sector by its own wave, speculatively without the marks the previous
   // sectors leave on its first five points; those marks only matter if the sector picked one of the marked points, which
   // the second pass detects (and then redoes that sector with the marks) in sector order
   constexpr int K6 = (NPAD / 6 + 2 + 63) / 64;
   for (int j = wave; j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);
   __syncthreads();
+  RF_T(3);   // first-pass selection
   if (wave == 0) {
     unsigned carry = (unsigned)s_misc[8];                                    // marks on the (up to 5) points after sector 0
     for (int j = 1; j < kSectors; ++j) {
@@ -703,6 +800,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     }
   }
 
+  RF_T(4);   // redo, labels, counts
   // ---- labels out (parity tests only) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
   if (a.store_debug) for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
 
@@ -806,14 +904,17 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     }
   }
   __syncthreads();
+  RF_T(5);   // bounding box + voxel indices
   // 32-bit run keys (voxel index << EB | first element) whenever the voxel box is small enough — most rings: half the LDS
   // traffic and a third fewer VALU instructions in the sort; the 64-bit keys remain for rings whose box has more cells.
   constexpr int EB = NPAD <= 2048 ? 11 : 12;                                  // bits of an element index
   float4* out = a.less_flat + (long long)b * a.cap;                          // final place: offset = less-flat points of the rings in front
-  if (!ALOAM_RF_KEYS64 && (overflow || cells_in_box <= (1ll << (32 - EB))))
-    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err);
-  else
-    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err);
+  if (!ALOAM_RF_KEYS64 && (overflow || cells_in_box <= (1ll << (32 - EB)))) {
+    // bits of a voxel index: every index is below cells_in_box (or, in PCL's overflow case, the element number itself)
+    const int key_bits = overflow ? EB : (cells_in_box > 1 ? 64 - __clzll(cells_in_box - 1) : 1);
+    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err, key_bits, rf_t_prev);
+  } else
+    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err, 0, rf_t_prev);
   // the picked points go straight to their final place in the three clouds, in the reference's order (ring, sector, pick order;
   // sharp = the first two less-sharp picks, :301-311)
   if (wave == 0) {
