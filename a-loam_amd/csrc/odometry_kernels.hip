@@ -589,9 +589,18 @@ __global__ __launch_bounds__(256) void k_transform_queries(OdomArgs a) {
 // workgroup 1.90 ms, 4: 1.63, 2: 1.53, 1: 1.47 — a freed SIMD slot is refilled soonest when nothing else has to retire with it.
 // Persistent waves (exactly the resident number, each walking through 1 / W of the queries of its XCD's sequences) were measured
 // too: 1.84 ms — the loop carries 75 VGPRs instead of 64 (6 waves per SIMD instead of 8) and the kernel lives off occupancy.
-template <bool PLANE, bool DISTORT>
+#ifndef ALOAM_ASSOC_SWEEP_WIDE
+#define ALOAM_ASSOC_SWEEP_WIDE 6     // rows of 64 candidates in flight per wave, planar class, sensors with more than 64 rings.  Measured on the
+                                     // 128 x 2048 stress sweeps (two launches, batch 1024): 3 rows 7.65 ms, 4: 7.70, 5: 7.14, 6: 6.64, 8: 8.69, 10: 11.8
+#endif
+#ifndef ALOAM_ASSOC_SWEEP_PLANE
+#define ALOAM_ASSOC_SWEEP_PLANE 3    // the same for sensors with up to 64 rings (HDL-64, batch 1024: 3 rows 2.83 ms, 4 rows 3.03 ms)
+#endif
+template <bool PLANE, bool WIDE> struct SweepRows { static constexpr int value = WIDE ? (PLANE ? ALOAM_ASSOC_SWEEP_WIDE : 3) : (PLANE ? ALOAM_ASSOC_SWEEP_PLANE : 2); };
+
+template <bool PLANE, bool DISTORT, bool WIDE>
 __device__ __forceinline__ void associate_one(const OdomArgs& a, int b, int qi, const SeqMeta& m, const GridView& g, int lane, int* row) {
-  constexpr int kSweep = PLANE ? 3 : 2;
+  constexpr int kSweep = SweepRows<PLANE, WIDE>::value;
   const int qcap = PLANE ? a.R * 24 : a.R * 12;
   const float4* Q = (PLANE ? a.flat : a.sharp) + (long long)b * qcap;
   const float4 raw = Q[qi];
@@ -741,13 +750,13 @@ __device__ __forceinline__ void associate_one(const OdomArgs& a, int b, int qi, 
   }
 }
 
-template <bool PLANE, bool DISTORT>
+template <bool PLANE, bool DISTORT, bool WIDE = false>
 __global__ __launch_bounds__(64) void k_associate(OdomArgs a) {
   // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs by linear id and every XCD has its own 4 MiB L2.
   // The grids of one sequence (~1.5 MB) are shared by all waves working on that sequence, so the linear id is re-mapped such that
   // XCD x works through sequences x, x+8, x+16, ...: each L2 holds a few sequences' grids instead of thrashing on all of them.
   // (Pure placement: any mapping gives the same result.)
-  constexpr int kSweep = PLANE ? 3 : 2;
+  constexpr int kSweep = SweepRows<PLANE, WIDE>::value;
   __shared__ int row[kSweep * 64];
   const int lane = threadIdx.x, L = blockIdx.x, xcd = L & 7, slot = L >> 3;
   const int qcap = PLANE ? a.R * 24 : a.R * 12;
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(64) void k_associate(OdomArgs a) {
   if (b >= a.B) return;
   const SeqMeta m = a.meta[b];
   if (qi >= (PLANE ? m.n_flat : m.n_sharp)) return;
-  associate_one<PLANE, DISTORT>(a, b, qi, m, grid_view(a, b, PLANE ? 1 : 0), lane, row);
+  associate_one<PLANE, DISTORT, WIDE>(a, b, qi, m, grid_view(a, b, PLANE ? 1 : 0), lane, row);
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -918,9 +927,15 @@ void launch_associate(const OdomArgs& a, bool plane, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
   const int qcap = plane ? a.R * 24 : a.R * 12;   // the kernel decodes (sequence, query) from blockIdx.x with exactly this slot count
   const dim3 grid((unsigned)(qcap * by)), block(64);
+  // sensors with more than 64 rings: the ring grid's +-2-ring window and the fine blocks hold about twice the candidates, so the
+  // waves keep more rows of 64 candidates in flight per sweep round (kSweep by class AND ring count)
+  const bool wide = a.R > 64;
   if (a.distortion) {
     if (plane) hipLaunchKernelGGL((k_associate<true, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_associate<false, true>), grid, block, 0, s, a);
+  } else if (wide) {
+    if (plane) hipLaunchKernelGGL((k_associate<true, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_associate<false, false, true>), grid, block, 0, s, a);
   } else {
     if (plane) hipLaunchKernelGGL((k_associate<true, false>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_associate<false, false>), grid, block, 0, s, a);

@@ -33,7 +33,7 @@ def _assert_pose_close(po, pg, ctx=""):
 
 
 @pytest.mark.parametrize("name,frames,kw", [("VLP-16", 4, {}), ("HDL-32", 3, {}), ("HDL-64", 4, {}), ("HDL-64", 3, {"columns": 2200}),
-                                            ("ROWS128", 2, {}), ("HDL-64", 4, {"rough": True}), ("VLP-16", 4, {"rough": True}),
+                                            ("ROWS128", 4, {}), ("HDL-64", 4, {"rough": True}), ("VLP-16", 4, {"rough": True}),
                                             ("HDL-64", 3, {"rough": True, "nan_fraction": 0.02, "columns": 1500})])
 def test_free_running_sequence_matches_oracle(O, binding, sequence, name, frames, kw):
     """Registration + odometry over consecutive sweeps, every intermediate array compared.  The `rough` cases are KITTI-shaped
