@@ -20,6 +20,7 @@
 //                 integration (:504-505).  One workgroup per sequence.
 // No step is a dense contraction (largest "matrix" is 3060 x 6), so no MFMA.
 #include "aloam_device.hpp"
+#include "aloam_trig.hpp"
 #include "lm_device.hpp"
 #include "odometry_kernels.hpp"
 
@@ -47,14 +48,17 @@ __device__ __forceinline__ void slerp_scales(double w, double s, double* c0, dou
   const double absD = fabs(w);
   if (absD >= one) { *c0 = 1.0 - s; *c1 = s; *dc0 = 0.0; *dc1 = 0.0; }
   else {
-    const double theta = acos(absD), st = sin(theta), ct = cos(theta);
+    // acos / sin / cos of aloam_trig.hpp: the same IEEE operations as the CPU side performs, so the scales — and with them the f32
+    // query points and the correspondences — are bit-identical by construction, not merely to an ulp of the device libm
+    const double theta = acos_port(absD), st = sin_port(theta), ct = cos_port(theta);
     const double a0 = (1.0 - s) * theta, a1 = s * theta;
-    *c0 = sin(a0) / st;
-    *c1 = sin(a1) / st;
+    const double s0 = sin_port(a0), s1 = sin_port(a1);
+    *c0 = s0 / st;
+    *c1 = s1 / st;
     // d/dtheta of sin(k theta) / sin(theta), then d theta / d absD = -1 / sin(theta), d absD / d w = sign(w)
     const double g = (w < 0.0 ? 1.0 : -1.0) / st;
-    *dc0 = ((1.0 - s) * cos(a0) * st - sin(a0) * ct) / (st * st) * g;
-    *dc1 = (s * cos(a1) * st - sin(a1) * ct) / (st * st) * g;
+    *dc0 = ((1.0 - s) * cos_port(a0) * st - s0 * ct) / (st * st) * g;
+    *dc1 = (s * cos_port(a1) * st - s1 * ct) / (st * st) * g;
   }
   if (w < 0.0) { *c1 = -*c1; *dc1 = -*dc1; }
 }

@@ -15,6 +15,9 @@
 #pragma once
 #include <cmath>
 #include <limits>
+// acos / sin / cos of the slerp (DISTORTION 1 only): the fixed IEEE operation sequence the device evaluates too, so that both sides get
+// the same bits (FDLIBM algorithms, within 1 ulp of glibc: tests/host/test_trig_port.cpp); the reference build under oracle/_ref keeps glibc.
+#include "../a-loam_amd/csrc/aloam_trig.hpp"
 
 namespace orc {
 
@@ -42,12 +45,12 @@ template <int N> inline Jet<N>& operator+=(Jet<N>& x, const Jet<N>& y) { x = x +
 template <int N> inline bool operator<(const Jet<N>& x, const Jet<N>& y) { return x.a < y.a; }
 template <int N> inline bool operator>=(const Jet<N>& x, const Jet<N>& y) { return x.a >= y.a; }
 template <int N> inline Jet<N> jsqrt(const Jet<N>& x) { Jet<N> r; r.a = std::sqrt(x.a); const double d = 0.5 / r.a; for (int k = 0; k < N; ++k) r.v[k] = x.v[k] * d; return r; }
-template <int N> inline Jet<N> jsin(const Jet<N>& x) { Jet<N> r; r.a = std::sin(x.a); const double d = std::cos(x.a); for (int k = 0; k < N; ++k) r.v[k] = x.v[k] * d; return r; }
-template <int N> inline Jet<N> jacos(const Jet<N>& x) { Jet<N> r; r.a = std::acos(x.a); const double d = -1.0 / std::sqrt(1.0 - x.a * x.a); for (int k = 0; k < N; ++k) r.v[k] = x.v[k] * d; return r; }
+template <int N> inline Jet<N> jsin(const Jet<N>& x) { Jet<N> r; r.a = aloam::sin_port(x.a); const double d = aloam::cos_port(x.a); for (int k = 0; k < N; ++k) r.v[k] = x.v[k] * d; return r; }
+template <int N> inline Jet<N> jacos(const Jet<N>& x) { Jet<N> r; r.a = aloam::acos_port(x.a); const double d = -1.0 / std::sqrt(1.0 - x.a * x.a); for (int k = 0; k < N; ++k) r.v[k] = x.v[k] * d; return r; }
 template <int N> inline Jet<N> jabs(const Jet<N>& x) { return x.a < 0.0 ? -x : x; }
 inline double jsqrt(double x) { return std::sqrt(x); }
-inline double jsin(double x) { return std::sin(x); }
-inline double jacos(double x) { return std::acos(x); }
+inline double jsin(double x) { return aloam::sin_port(x); }
+inline double jacos(double x) { return aloam::acos_port(x); }
 inline double jabs(double x) { return std::fabs(x); }
 inline double jval(double x) { return x; }
 template <int N> inline double jval(const Jet<N>& x) { return x.a; }

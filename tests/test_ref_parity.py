@@ -244,7 +244,9 @@ def test_oracle_functors_with_interpolation_ratio_match_reference_templates(O):
         P = np.array([[w, z, -y], [-z, w, x], [y, -x, w], [-x, -y, -z]])
         Jref = np.concatenate([jq[i, :rows] @ P, jt[i, :rows]], axis=1)
         scale = max(1.0, np.abs(Jref).max())
-        assert np.array_equal(r, res[i, :rows]), (i, r, res[i, :rows])             # same operations in the same order: bit-exact
+        # same operations in the same order; the only difference is sin / acos inside the slerp: the reference build calls glibc, the
+        # oracle the restatement it shares with the device (a-loam_amd/csrc/aloam_trig.hpp, within 1 ulp of glibc) -> a few ulp here
+        assert np.abs(r - res[i, :rows]).max() <= 16 * np.finfo(float).eps * max(1.0, np.abs(res[i, :rows]).max()), (i, r, res[i, :rows])
         worst = max(worst, np.abs(J - Jref).max() / scale)
     assert worst < 1e-12, worst
 
