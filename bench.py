@@ -48,7 +48,7 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
 STAGE_KERNELS = {"map_associate": ["k_map_search<0>", "k_map_search<1>", "k_map_fit<0>", "k_map_fit<1>"],   # a profiled stage = these kernels, once each
                  "map_solve": ["k_map_solve"], "map_register": ["k_map_register"], "map_begin": ["k_map_begin"],
-                 "map_grid": ["k_mapgrid_count", "k_mapgrid_scan", "k_mapgrid_fill"]}
+                 "map_grid": ["k_mapgrid_build"], "k_build_grids": ["k_build_grids_fused", "k_build_grids"]}
 RK_NAMES = {"k_associate[plane]": "k_associate<true, false>", "k_associate[corner]": "k_associate<false, false>",
             "k_ring_features": "k_ring_features<2048>", "k_solve": "k_solve<false>"}
 
