@@ -6,13 +6,14 @@
 //                      no longer fits behind the bump pointer
 //   k_map_begin        :142-146 transformAssociateToMap, :311-321 centre cube, :323-507 window shifts (the 21 x 21 x 11
 //                      pointer grid becomes a table of cube descriptors), :509-539 valid cubes + submap prefixes
-//   k_vox_*            pcl::VoxelGrid::filter (:542-550 incoming clouds, :788-801 per-cube re-filter): bounding box ->
-//                      (voxel, index) 64-bit keys -> tile sort in LDS + rank-merge levels -> segment heads -> centroids in
-//                      input order; any number of independent segments per launch
-//   k_mapgrid_*        pcl::KdTreeFLANN::setInputCloud (:558-559): 2 m cell hash over the submap (global counting sort)
+//   k_vox_lds          pcl::VoxelGrid::filter (:542-550 incoming clouds, :788-801 per-cube re-filter) of one segment by one workgroup:
+//                      run heads -> (voxel, first point) keys -> stable radix sort in registers / LDS -> centroids in input order
+//   k_vox_*            the same through global memory for segments that do not fit (tile sort + rank-merge levels)
+//   k_mapgrid_build    pcl::KdTreeFLANN::setInputCloud (:558-559): 2 m cell hash over the submap, LDS counting sort per (sequence,
+//                      class); k_mapgrid_count/scan/fill: the global-atomic form for tables that do not fit the LDS
 //   k_map_search/_fit  :576-706  pointAssociateToMap, nearestKSearch(k = 5) as an exact fixed-radius search (the reference
 //                      only uses the result when the 5th neighbour is closer than 1 m), line fit (3x3 symmetric
-//                      eigen-decomposition) / plane fit (5x3 least squares), factor records
+//                      eigen-decomposition) / plane fit (5x3 least squares), valid factor records compacted per tile of 256 points
 //   k_map_solve        :565-572,712-720 ceres::Solve over LidarEdgeFactor + LidarPlaneNormFactor blocks (shared LM loop,
 //                      lm_device.hpp), then :148-152 transformUpdate
 //   k_map_cubeid / k_map_reserve / k_map_scatter   :737-783 map insertion (stable append per cube)

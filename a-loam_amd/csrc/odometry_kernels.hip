@@ -2,7 +2,8 @@
 //
 // Replaces, for a BATCH of independent sequences, the solve part of the laserOdometry main loop
 // (reference src/laserOdometry.cpp:274-506) and the third-party calls inside it:
-//   k_build_grids pcl::KdTreeFLANN::setInputCloud (:567-568): LDS counting-sort of each "last" cloud into two spatial
+//   k_build_grids_fused / k_build_grids
+//                 pcl::KdTreeFLANN::setInputCloud (:567-568): LDS counting-sort of each "last" cloud into two spatial
 //                 hash grids (3-D cells on two levels, (x, y, ring) cells) + the flag that says whether the cloud is ring-sorted, which is what turns
 //                 the reference's walk-until-break loops into "ring key within +-2" tests
 //   k_associate   TransformToStart (:111-129) + nearestKSearch(k=1) (:302,390) + the ring-adjacent second / third

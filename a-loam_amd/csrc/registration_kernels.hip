@@ -5,7 +5,7 @@
 //   k_find_ends       :136-153   first / last kept point, startOri / endOri
 //   k_classify        :85-112,160-236  NaN + range filter, ring id, raw azimuth, halfPassed flip index,
 //                                per-block ring histograms
-//   k_ring_offsets    :246-252   ring start offsets (exclusive scans of the histograms)
+//   k_ring_offsets    :246-252   ring start offsets (exclusive scans of the histograms over the blocks, lanes across the rings)
 //   k_scatter         :208-241   relTime -> intensity, STABLE per-ring compaction into the ring-ordered cloud
 //   k_ring_features   :256-407   one workgroup per (sweep, ring): 11-tap curvature from alternating 266-point LDS
 //                                tiles; std::sort + greedy corner / flat picking with neighbour suppression evaluated as
