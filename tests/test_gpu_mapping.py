@@ -250,3 +250,41 @@ def test_capacity_errors_of_unsynchronised_steps_are_not_lost(binding):
     assert sum(len(v) for v in gpu.map_cubes(1, 1).values()) >= held       # the earlier map is intact
     assert sum(len(v) for v in gpu.map_cubes(1, 0).values()) > 50           # and the later, fitting step was inserted
     gpu.close()
+
+
+@pytest.mark.parametrize("case", ["many_runs", "far_point", "voxel_overflow", "big_segment"])
+def test_voxel_filter_segments_the_lds_kernel_hands_to_the_general_path(O, binding, case):
+    """k_vox_lds takes a segment only when its runs fit the LDS, its coordinates keep floor(p / leaf) an exact f32 integer below 2^23
+    and it has at most 65535 points; everything else must come out of the tile-sort / rank-merge path of round 2 — unchanged results:
+    the down-sampled incoming clouds (laserCloudCornerStack / SurfStack, reference src/laserMapping.cpp:542-550) and the re-filtered
+    cubes (:788-801) bit for bit against the oracle, solver off."""
+    rng = np.random.default_rng(17)
+    cap = 90000
+    orc = O.Oracle(16, 0.3, lm_max_iterations=0)
+    orc.map_config(0.4, 0.8)
+    gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=1, max_points=cap, lm_max_iterations=0)
+    gpu.mapping_enable(0.4, 0.8, pool_points=262144)
+    corner = rng.uniform(-30, 30, (1500, 4)).astype(np.float32); corner[:, 3] = np.sort(rng.integers(0, 16, 1500))
+    if case == "many_runs":            # 30 000 scattered points: every point its own run, more than the 24 576 the LDS holds
+        surf = rng.uniform(-60, 60, (30000, 4)).astype(np.float32); surf[:, 2] *= 0.05
+    elif case == "far_point":          # one coordinate beyond 2^23 leaves: the exact-integer argument of the cell test does not hold
+        surf = rng.uniform(-20, 20, (5000, 4)).astype(np.float32); surf[:, 2] *= 0.05
+        surf[1234, 0] = 7.5e6
+    elif case == "voxel_overflow":     # more than 2^31 voxels in the box: pcl::VoxelGrid returns its input unfiltered
+        surf = rng.uniform(-20, 20, (3000, 4)).astype(np.float32)
+        surf[7, :3] = (3.0e5, 3.0e5, 3.0e5); surf[8, :3] = (-3.0e5, -3.0e5, -3.0e5)   # 7.5e5 leaves per axis: 4e17 voxels (no 64-bit wrap)
+    else:                              # more points than the 16-bit point index of a run key addresses
+        surf = rng.uniform(-40, 40, (80000, 4)).astype(np.float32); surf[:, 2] *= 0.02
+    surf[:, 3] = np.sort(rng.integers(0, 16, len(surf)))
+    for k in range(2):                 # two frames: the second one re-filters cubes that already hold points
+        q, t = np.array([0, 0, 0, 1.0]), np.array([0.05 * k, 0, 0])
+        orc.mapping_step(q, t, corner, surf, surf[:10])
+        gpu.set_last(corner, surf, 0); gpu.set_full_cloud(surf[:10], 0); gpu.set_state([0, 0, 0, 1], [0, 0, 0], q, t, 0)
+        gpu.mapping_step()
+        gpu.synchronize()
+        so, sg = orc.map_cloud(O.MAP_SURF_STACK), gpu.map_cloud(binding.MAP_SURF_STACK)
+        assert so.shape == sg.shape and bits_equal(so, sg), (case, k, so.shape, sg.shape)
+        assert bits_equal(orc.map_cloud(O.MAP_CORNER_STACK), gpu.map_cloud(binding.MAP_CORNER_STACK)), (case, k)
+        for cls in (0, 1):
+            _compare_maps(gpu.map_cubes(cls), orc.map_cubes(cls), (case, k, cls))
+    gpu.close()
