@@ -117,13 +117,19 @@ __device__ __forceinline__ void deskew_jacobian_row(const double a[3], const dou
 // with LDS counting sort (count -> exclusive scan -> fill):
 //   G3: key (ix, iy, iz)      cell kCell3 + a coarse level — exact 1-NN by expanding cubic shells
 //   G2: key (ix, iy, ringkey) cell kCell2                  — the ring-adjacent second / third neighbour search
-// A grid entry is {x, y, z, bits(idx | (ringkey + 1) << 20)}: one 16-B load per candidate.  Cell sizes are dyadic
-// (0.5, 1, 2, 4, 2.625 = 21/8), so cell borders are exact f32 values; skipping a cell by its distance still leaves a margin.
+// A grid entry is {x, y, z, bits(idx | (ringkey + 1) << 20)}: one 16-B load per candidate.  Cell sizes have few
+// mantissa bits (0.5, 0.75, 2, 3, 2.625 = 21/8), so cell borders are exact f32 values; skipping a cell by its distance still leaves a margin.
 // Also per cloud: flags[1] = the cloud is NOT ring-sorted (ring key = int(intensity) never decreasing with the index, the
 // way scan registration emits it).  On ring-sorted clouds the reference's walk-until-break loops visit exactly the points
 // whose key lies within +-2 of the closest point's; clouds that are not sorted (possible through aloam_set_last) take the
 // literal walks, and clouds with huge coordinates or keys (flags[0]) the literal brute-force search as well.
-constexpr float kCell3Surf = 0.5f, kCell3Corner = 1.0f;
+#ifndef ALOAM_CELL3_SURF
+#define ALOAM_CELL3_SURF 0.5f      // A/B builds (values with few mantissa bits only: cell borders must be exact f32 numbers)
+#endif
+#ifndef ALOAM_CELL3_CORNER
+#define ALOAM_CELL3_CORNER 0.75f   // measured (k_associate[corner], two launches, batch 1024): 1.25 m 1.13 ms, 1.0 m 1.106, 0.75 m 1.048, 0.625 m 1.074, 0.5 m 1.159;
+#endif                             // the planar class: 0.375 m 2.90 ms, 0.5 m 2.84, 0.625 m 3.01
+constexpr float kCell3Surf = ALOAM_CELL3_SURF, kCell3Corner = ALOAM_CELL3_CORNER;
 // A 1-NN query whose neighbour is not inside the first block of fine cells continues on cells four times as large, so the work
 // of a far query is bounded by a few dozen bucket look-ups instead of growing with the cube of the radius.  The ring grid has
 // one level of 2.625 m cells: its 3x3 block already settles 95 % of the searches that reach it (most never do: the fine 1-NN
