@@ -1169,11 +1169,26 @@ __device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[
 
 }  // namespace
 
+#ifndef ALOAM_MAP_SEARCH_U
+#define ALOAM_MAP_SEARCH_U 4      // A/B builds: loads in flight per lane (measured, map_associate per step: 2: 7.76 ms, 4: 6.91, 6: 7.09, 8: 7.01)
+#endif
+#ifndef ALOAM_MAP_SEARCH_XCD
+#define ALOAM_MAP_SEARCH_XCD 1    // A/B builds: 0 = plain (block, sequence) grid
+#endif
 // Search half: lane per query, few registers, so that many waves hide the latency of the bucket walks.  Writes the five
 // neighbours (x, y, z each; ascending (distance, index)) or a "not found" mark to a.knn[query].
 template <int CLS>
-__global__ __launch_bounds__(256) void k_map_search(MapArgs a) {
-  const int b = blockIdx.y;
+__global__ __launch_bounds__(256) void k_map_search(MapArgs a, int nblk) {
+  // XCD-aware work mapping (as in k_associate): workgroups are dealt round-robin over the 8 XCDs by linear id, and every XCD has its
+  // own L2.  The bucketed submap of a sequence (~0.7 MB) is read by all of that sequence's workgroups, so the 1-D grid is decoded
+  // such that XCD x works through sequences x, x + 8, ...: one L2 fetches a sequence's submap instead of eight.
+#if ALOAM_MAP_SEARCH_XCD
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int b = (slot / nblk) * 8 + xcd, blk = slot % nblk;
+  if (b >= a.B) return;
+#else
+  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+#endif
   const MapSeq& ms = a.seq[b];
   const int n = ms.n_stack[CLS];
   const long long sb = (long long)b * (CLS == 0 ? a.R * 120 : a.cap);
@@ -1184,7 +1199,7 @@ __global__ __launch_bounds__(256) void k_map_search(MapArgs a) {
   const int H = a.grid_H[CLS];
   const int* __restrict__ start = a.grid_start[CLS] + (long long)b * (H + 1);
   const float4* __restrict__ sorted = a.grid_sorted[CLS] + (long long)b * a.pool_cap;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {   // grid-stride over the stack
+  for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) {          // grid-stride over the stack
     const float4 sel = associate_to_map(a.stack[CLS][sb + i], par);        // pointSel (:580, :646)
     const float gx = sel.x * kMapCellInv, gy = sel.y * kMapCellInv, gz = sel.z * kMapCellInv;
     const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
@@ -1214,7 +1229,7 @@ __global__ __launch_bounds__(256) void k_map_search(MapArgs a) {
       const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;                   // FLANN L2_Simple, f32
       if (d < 1.0f) top.insert(d, __float_as_int(p.w), p.x, p.y, p.z);
     };
-    constexpr int U = 4;                                                     // independent loads in flight per lane
+    constexpr int U = ALOAM_MAP_SEARCH_U;                                    // independent loads in flight per lane
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       for (int k = s0[c]; k < s1[c]; k += U) {
@@ -1639,9 +1654,10 @@ void launch_map_grid(const MapArgs& a, hipStream_t s) {
 }
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
   (void)iter;
-  hipLaunchKernelGGL(k_map_search<0>, dim3(16, a.B), dim3(256), 0, s, a);
+  const int by = (a.B + 7) / 8 * 8;                      // padded so that every (XCD, sequence slot) pair exists
+  hipLaunchKernelGGL(k_map_search<0>, dim3(16 * by), dim3(256), 0, s, a, 16);
   hipLaunchKernelGGL(k_map_fit<0>, dim3(16, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_map_search<1>, dim3(48, a.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_map_search<1>, dim3(48 * by), dim3(256), 0, s, a, 48);
   hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) {
