@@ -94,22 +94,35 @@ __global__ __launch_bounds__(256) void k_map_compact_plan(MapArgs a) {
   constexpr int PER = (kMapCubes + 255) / 256;
   if (tid < 3) s_sum[tid] = 0;
   __syncthreads();
-  int need = 0, roomy = 0, tight = 0;
+  // First only what this frame asks for: the descriptors of the dozen cubes that receive points (the append counts of all 4851
+  // cubes are 19 KB per class, their descriptors 78 KB: reading those every frame although a compaction is rare was 1.7 GB per
+  // launch).  The sums over ALL cubes are formed only when the reservations do not fit behind the bump pointer.
+  int need = 0;
   for (int k = 0; k < PER; ++k) {
     const int c = tid * PER + k;
     if (c >= kMapCubes) break;
-    const CubeDesc d = T[c];
-    const int ad = add[c], n = d.cnt + (ad > 0 ? ad : 0);
-    if (ad > 0 && n > d.cap) need += 2 * n < 256 ? 256 : 2 * n;            // what k_map_reserve would take
+    const int ad = add[c];
+    if (ad > 0) {
+      const CubeDesc d = T[c];
+      const int n = d.cnt + ad;
+      if (n > d.cap) need += 2 * n < 256 ? 256 : 2 * n;                      // what k_map_reserve would take
+    }
+  }
+  if (need) atomicAdd(&s_sum[0], need);
+  __syncthreads();
+  if (ms.pool_used[cls] + s_sum[0] <= a.pool_cap) { if (tid == 0) *flag = 0; return; }   // fits as it is: the normal frame
+  int roomy = 0, tight = 0;
+  for (int k = 0; k < PER; ++k) {
+    const int c = tid * PER + k;
+    if (c >= kMapCubes) break;
+    const int ad = add[c], n = T[c].cnt + (ad > 0 ? ad : 0);
     roomy += compact_cap(n, 1);
     tight += compact_cap(n, 2);
   }
-  if (need) atomicAdd(&s_sum[0], need);
   if (roomy) { atomicAdd(&s_sum[1], roomy); atomicAdd(&s_sum[2], tight); }
   __syncthreads();
-  int mode = 0;
-  if (ms.pool_used[cls] + s_sum[0] > a.pool_cap) mode = s_sum[1] <= a.pool_cap ? 1 : (s_sum[2] <= a.pool_cap ? 2 : 0);
-  if (mode == 0) { if (tid == 0) *flag = 0; return; }                       // fits as it is, or really full (k_map_reserve reports that)
+  const int mode = s_sum[1] <= a.pool_cap ? 1 : (s_sum[2] <= a.pool_cap ? 2 : 0);
+  if (mode == 0) { if (tid == 0) *flag = 0; return; }                       // really full (k_map_reserve reports that)
   int local = 0;
   for (int k = 0; k < PER; ++k) { const int c = tid * PER + k; if (c < kMapCubes) { const int ad = add[c]; local += compact_cap(T[c].cnt + (ad > 0 ? ad : 0), mode); } }
   s_part[tid] = local;
@@ -1172,6 +1185,12 @@ __device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[
 #ifndef ALOAM_MAP_SEARCH_U
 #define ALOAM_MAP_SEARCH_U 4      // A/B builds: loads in flight per lane (measured, map_associate per step: 2: 7.76 ms, 4: 6.91, 6: 7.09, 8: 7.01)
 #endif
+#ifndef ALOAM_MAP_SEARCH_NBLK0
+#define ALOAM_MAP_SEARCH_NBLK0 16  // workgroups per sequence, corner / surf class (A/B builds)
+#endif
+#ifndef ALOAM_MAP_SEARCH_NBLK1
+#define ALOAM_MAP_SEARCH_NBLK1 48
+#endif
 #ifndef ALOAM_MAP_SEARCH_XCD
 #define ALOAM_MAP_SEARCH_XCD 1    // A/B builds: 0 = plain (block, sequence) grid
 #endif
@@ -1655,9 +1674,9 @@ void launch_map_grid(const MapArgs& a, hipStream_t s) {
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
   (void)iter;
   const int by = (a.B + 7) / 8 * 8;                      // padded so that every (XCD, sequence slot) pair exists
-  hipLaunchKernelGGL(k_map_search<0>, dim3(16 * by), dim3(256), 0, s, a, 16);
+  hipLaunchKernelGGL(k_map_search<0>, dim3(ALOAM_MAP_SEARCH_NBLK0 * by), dim3(256), 0, s, a, ALOAM_MAP_SEARCH_NBLK0);
   hipLaunchKernelGGL(k_map_fit<0>, dim3(16, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_map_search<1>, dim3(48 * by), dim3(256), 0, s, a, 48);
+  hipLaunchKernelGGL(k_map_search<1>, dim3(ALOAM_MAP_SEARCH_NBLK1 * by), dim3(256), 0, s, a, ALOAM_MAP_SEARCH_NBLK1);
   hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) {
