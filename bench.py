@@ -49,8 +49,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievab
 STAGE_KERNELS = {"map_associate": ["k_map_search<0>", "k_map_search<1>", "k_map_fit<0>", "k_map_fit<1>"],   # a profiled stage = these kernels, once each
                  "map_solve": ["k_map_solve"], "map_register": ["k_map_register"], "map_begin": ["k_map_begin"],
                  "map_grid": ["k_mapgrid_build"], "k_build_grids": ["k_build_grids_fused", "k_build_grids"]}
-RK_NAMES = {"k_associate[plane]": "k_associate<true, false>", "k_associate[corner]": "k_associate<false, false>",
-            "k_ring_features": "k_ring_features<2048>", "k_solve": "k_solve<false>"}
+RK_NAMES = {"k_associate[plane]": "k_associate<true, false", "k_associate[corner]": "k_associate<false, false",      # profiled name -> prefix of the
+            "k_ring_features": "k_ring_features<", "k_solve": "k_solve<false>"}                                     # kernel name rocprofv3 reports
 
 
 def quat_angle(qa, qb):
@@ -233,7 +233,7 @@ def roofline_of(prof, steps, B, sensor, mapping):
         except (OSError, ValueError):
             continue
         if pm.get("batch") == B and pm.get("mapping") == bool(mapping) and pm.get("sensor") == sensor:
-            cands = STAGE_KERNELS.get(dname) or [k for k in pm.get("fetch_kib", {}) if k == RK_NAMES.get(dname, dname) or k.split("<")[0] == dname][:1]
+            cands = STAGE_KERNELS.get(dname) or [k for k in pm.get("fetch_kib", {}) if k.startswith(RK_NAMES.get(dname, dname + "<")) or k == dname][:1]
             if cands and all(k in pm.get("fetch_kib", {}) and k in pm.get("write_kib", {}) for k in cands):
                 r["traffic"] = round(sum(2.0 * pm["fetch_kib"][k] + pm["write_kib"][k] for k in cands) * 1024.0)
                 r["traffic_source"] = pm.get("source", "profiles/")
