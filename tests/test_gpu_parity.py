@@ -514,3 +514,35 @@ def test_ring_count_lookback_survives_concurrent_streams():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["steps"] == 200 and line["config"]["contexts_per_gpu"] == 4 and line["value"] > 1000
+
+
+def test_two_ranks_shard_sequences_on_the_hip_path(binding, syn, tmp_path):
+    """The N > 1 layout with the HIP path underneath: two processes (gloo control plane, both on this box's one GPU), sequence s on rank
+    s mod 2, each rank with its own context over ITS sequences only; the gathered pose table must equal, bit for bit, what one context
+    over all five sequences computes — sequences never interact, whichever process or batch slot they run in."""
+    import socket
+    import subprocess
+    import sys
+    n_seq, frames = 5, 3
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(root, "tests", "gpu_shard_worker.py"), str(n_seq), str(frames), str(tmp_path)], env=env))
+    assert all(p.wait(timeout=600) == 0 for p in procs)
+    t0, t1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(t0, t1)                                            # every rank holds the same gathered table
+    seqs = [syn.make_sequence("VLP-16", frames, seed=70 + g, columns=600) for g in range(n_seq)]
+    model = seqs[0][3]
+    gpu = binding.Aloam(n_scans=model.n_scans, min_range=model.min_range, batch=n_seq, max_points=16 * 600 + 64)
+    for k in range(frames):
+        gpu.scan_register([s[0][k].numpy() for s in seqs])
+        gpu.odometry_step()
+    gpu.synchronize()
+    ref = np.array([np.r_[gpu.pose(b)["t_w"], gpu.pose(b)["q_w"]] for b in range(n_seq)])
+    gpu.close()
+    assert np.array_equal(t0, ref), np.abs(t0 - ref).max()
+    assert np.all(np.linalg.norm(ref[:, :3], axis=1) > 0.5)                  # and every sequence moved
