@@ -93,6 +93,7 @@ def parse_args():
 
 # ---------------------------------------------------------------------------------------------------------------------
 SHARED_GPU_ENV = "ALOAM_BENCH_SHARED_GPU"   # test hook: let the ranks share the visible devices (control plane on gloo) on a 1-GPU box
+FORCE_DIST_ENV = "ALOAM_BENCH_FORCE_DIST"    # test hook: initialise the process group (nccl = RCCL) and run barrier + MAX even when WORLD_SIZE is 1
 RANK_ENV_ONLY = "ALOAM_BENCH_RANK_ENV_ONLY"  # test hook: a started rank prints the environment it was given and exits (no GPU needed)
 
 
@@ -182,7 +183,7 @@ def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping):
     for cx in ctxs:
         cx.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist is not None:
         dist.barrier()
     if NC == 1:
         ctxs[0].profile_enable(True)                       # per-kernel hipEvents serialise nothing on one stream; with several
@@ -193,7 +194,7 @@ def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping):
         cx.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else wl.data.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -472,7 +473,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get(FORCE_DIST_ENV):       # (test hook: the control plane also with a single rank, e.g. RCCL on the one GPU of the box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if shared:
@@ -561,7 +562,7 @@ def main():
             "roofline": roofline_of(prof3, steps2, B, "ROWS128", False), "input_generation_s": round(wl3.gen_s, 2)}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

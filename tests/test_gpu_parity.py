@@ -546,3 +546,32 @@ def test_two_ranks_shard_sequences_on_the_hip_path(binding, syn, tmp_path):
     gpu.close()
     assert np.array_equal(t0, ref), np.abs(t0 - ref).max()
     assert np.all(np.linalg.norm(ref[:, :3], axis=1) > 0.5)                  # and every sequence moved
+
+
+def test_driver_launch_form_with_the_rccl_control_plane(tmp_path):
+    """The exact launch form the driver uses for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` — with N = 1, the only N this box has, and the process group forced on
+    (ALOAM_BENCH_FORCE_DIST): `nccl` (= RCCL) initialisation on the rank's device, the barriers around the timed region and the MAX
+    all-reduce of the elapsed time all execute.  What stays unexecuted here is only RCCL between two devices."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, ALOAM_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "1", "--batch", "64", "--steps", "4", "--warmup", "2", "--frames", "3", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["value"] > 1000
+    out_dir = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "launcher_rccl_one_rank.json"), "w") as f:
+            json.dump({"how": "ALOAM_BENCH_FORCE_DIST=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port P bench.py --gpus 1 --batch 64 "
+                              "--steps 4 --warmup 2 --frames 3 --no-cpu-baseline --no-extras (nccl = RCCL process group of one rank: init, barrier, MAX all-reduce)", "line": line}, f, indent=1)
