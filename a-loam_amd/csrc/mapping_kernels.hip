@@ -1586,25 +1586,39 @@ __global__ __launch_bounds__(64) void k_map_scatter(MapArgs a) {
   const int* cur = a.cursor + ((long long)b * 2 + cls) * kMapCubes;
   float4* pool = a.pool[cls] + (long long)b * a.pool_cap;
   const long long sb = (long long)b * (cls == 0 ? a.R * 120 : a.cap);
-  __shared__ int s_cur[kMapCubes];
-  for (int c = lane; c < kMapCubes; c += 64) s_cur[c] = add[c] < 0 ? -1 : cur[c];
+  __shared__ int s_cur[kMapCubes];                                           // absolute append position of every touched cube (-1: no room, skipped)
+  for (int c = lane; c < kMapCubes; c += 64) {
+    const int ad = add[c];
+    s_cur[c] = ad > 0 ? T[c].off + cur[c] : -1;                              // (descriptor and cursor only of the dozen cubes that receive points)
+  }
   __syncthreads();
-  for (int base = 0; base < n; base += 64) {
-    const int i = base + lane;
-    int id = -1;
-    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) { id = a.stack_cube[cls][sb + i]; w = a.stack_world[cls][sb + i]; }
-    unsigned long long todo = __ballot(id >= 0);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int c = __shfl(id, leader, 64);
-      const unsigned long long same = __ballot(id == c);
-      const int start = s_cur[c];
-      if (id == c && start >= 0) pool[T[c].off + start + __popcll(same & ((1ull << lane) - 1ull))] = w;
-      __syncthreads();
-      if (lane == leader && start >= 0) s_cur[c] = start + __popcll(same);
-      __syncthreads();
-      todo &= ~same;
+  constexpr int U = 4;                                                       // rows of 64 points fetched ahead: one wave per (sequence, class) lives
+  for (int base0 = 0; base0 < n; base0 += 64 * U) {                          // off memory latency, so the loads of four rows are in flight together
+    int ids[U];
+    float4 ws[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base0 + u * 64 + lane;
+      ids[u] = -1;
+      ws[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n) { ids[u] = a.stack_cube[cls][sb + i]; ws[u] = a.stack_world[cls][sb + i]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int id = ids[u];
+      const float4 w = ws[u];
+      unsigned long long todo = __ballot(id >= 0);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int c = __shfl(id, leader, 64);
+        const unsigned long long same = __ballot(id == c);
+        const int start = s_cur[c];
+        if (id == c && start >= 0) pool[start + __popcll(same & ((1ull << lane) - 1ull))] = w;
+        __syncthreads();
+        if (lane == leader && start >= 0) s_cur[c] = start + __popcll(same);
+        __syncthreads();
+        todo &= ~same;
+      }
     }
   }
   __syncthreads();
