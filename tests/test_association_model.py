@@ -178,7 +178,8 @@ def _cloud(rng, n, rings, extent, voxel):
 
 
 @pytest.mark.parametrize("plane,cell3,H,seed", [(True, 0.5, 256, 1), (True, 0.5, 4096, 2), (False, 1.0, 128, 3), (False, 1.0, 2048, 4),
-                                                (True, 0.5, 64, 5), (False, 1.0, 32, 6)])
+                                                (True, 0.5, 64, 5), (False, 1.0, 32, 6),
+                                                (False, 0.75, 2048, 7), (False, 0.75, 128, 8), (False, 0.75, 32, 9)])   # round 3: the corner class uses 0.75 m cells (1 / 0.75 is not an exact f32)
 def test_grid_search_model_equals_the_walk_until_break_definition(plane, cell3, H, seed):
     rng = np.random.default_rng(seed)
     for trial in range(4):
