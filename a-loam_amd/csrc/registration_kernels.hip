@@ -338,10 +338,143 @@ __device__ __forceinline__ int gather_counts(const unsigned long long* slots, in
 // src/scanRegistration.cpp:284-390).  std::sort + "walk from the top, skip picked points" is evaluated as an iterative arg-max
 // over the still-unpicked points (arg-min for the flat points): same picks in the same order — ties in curvature go to the
 // larger index for corners and to the smaller one for flats, exactly what an ascending sort by (curvature, index) gives — no
-// sort, no LDS traffic between two picks.  Point `pos` of the sector lives in register pos / 64 of lane pos % 64, so a pick
-// at (register kr, lane f) can only touch registers kr-1, kr, kr+1 and the marks become three lane-distance tests.
+// sort, no LDS traffic between two picks.  Point `pos` of the sector lives in register pos / 64 of lane pos % 64.
 //   init_marks : bit p set = point p (p < 5) of this sector was already marked by picks of the sectors before it
 //   returns (through LDS) the picks, their counts and the marks this sector leaves on the five points behind it
+//
+// The loop body is what k_ring_features spends most of its VALU issue slots on (up to 20 + 4 picks per sector, 6 sectors per
+// ring), so it is written for instruction count:
+//   * a picked or marked point never comes back (cloudNeighborPicked is shared by the corner and the flat walk), so "dead" is
+//     folded into the key itself: the corner walk keeps curvature bits + 1 with 0 = dead (the per-lane maximum is a v_max3 chain,
+//     no mask tests), and one subtraction turns that into the key of the flat walk, curvature bits with 0xffffffff = dead;
+//   * `(double)c > 0.1` for a non-negative float c is `bits(c) >= bits(0.1f)` (0.1f is the float above 0.1, the float below it is
+//     below 0.1) and `bits(c) <= bits(inf)` for the NaNs; likewise `(double)c < 0.1` is `bits(c) < bits(0.1f)`: scalar integer
+//     compares on the wave-uniform extreme;
+//   * the register of the extreme inside its lane is computed per lane next to the DPP ladder (it fills the ladder's wait states);
+//   * a pick at register kr of lane f can only touch registers kr - 1, kr, kr + 1, and kr is wave-uniform: the keys sit in one
+//     register tuple that is indexed through the VGPR index mode (s_set_gpr_idx_on), one compare and one select per touched register
+//     (the neighbours only when the reach leaves lanes 0 .. 63, one pick of six);
+//   * the picks collect in one VGPR (lane = pick number) and go to LDS once.
+#ifndef ALOAM_RF_PICK
+#define ALOAM_RF_PICK 2         // A/B builds: 1 = the round-2 loop (alive bit mask, curvature compared as double)
+#endif
+constexpr unsigned kCurvThresholdBits = 0x3DCCCCCDu;                          // bits(0.1f); tests/host/test_trig_port.cpp checks the claim above
+constexpr unsigned kInfBits = 0x7f800000u;
+#if ALOAM_RF_PICK == 2
+template <int K6>
+__device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, int lane, const float* curv_l, const unsigned char* flags,
+                                            short* s_pick, int* s_misc) {
+  constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
+  constexpr int NRP = (K6 + 3) / 4;                                           // reach bytes packed 4 x 8 bit per register
+  const int sp = (L * j) / 6, len = (L * (j + 1)) / 6 - sp;
+  const int first = sp + 5;                                                   // local index of the sector's first point
+  typedef unsigned keys_t __attribute__((ext_vector_type(16)));               // > 8 elements: cc[kr] with a wave-uniform kr is one indexed v_mov
+  static_assert(K6 <= 16, "sector registers");
+  keys_t cc;                                                                  // corner walk: curvature bits + 1, 0 = dead
+  unsigned rp[NRP];
+#pragma unroll
+  for (int q = 0; q < NRP; ++q) rp[q] = 0;
+#pragma unroll
+  for (int r = 0; r < K6; ++r) {
+    const int pos = r * 64 + lane;
+    cc[r] = 0u;
+    if (pos < len) {
+      const int i = first + pos;
+      rp[r / 4] |= (unsigned)(flags[i] >> 2) << (8 * (r % 4));
+      if (!(pos < 5 && ((init_marks >> pos) & 1u))) cc[r] = __float_as_uint(curv_l[i]) + 1u;
+    }
+  }
+  unsigned spill = 0;
+  // the pick at register kr of lane f (both wave-uniform) marks itself and its reach dead; returns its position in the sector.
+  // The scalar side is kept as short as the vector side (the SALU issues one instruction per SIMD slot, like the VALU): the common
+  // case — reach inside lanes 0 .. 63, pick not within five points of the sector end — costs two compares and two branches not taken.
+  auto kill = [&](int kr, int f, const unsigned dead) {
+    unsigned rb;
+    if constexpr (NRP <= 2) {
+      const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)rp[0], f), r1 = (unsigned)__builtin_amdgcn_readlane((int)rp[NRP - 1], f);
+      rb = (unsigned)((((unsigned long long)r1 << 32) | r0) >> (8 * kr));
+    } else {
+      unsigned rpk = (unsigned)__builtin_amdgcn_readlane((int)rp[0], f);
+#pragma unroll
+      for (int q = 1; q < NRP; ++q) { const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)rp[q], f); if (q == (kr >> 2)) rpk = x; }
+      rb = rpk >> (8 * (kr & 3));
+    }
+    const int fw = (int)(rb & 7u), bk = (int)((rb >> 3) & 7u);
+    const int P = kr * 64 + f;
+    const int lo = f - bk, w = fw + bk;                                       // lanes lo .. lo + w of register kr (may stick out of 0 .. 63)
+    {
+      const bool in = (unsigned)(lane - lo) <= (unsigned)w;
+      const unsigned old = cc[kr];                                            // VGPR index mode (kr is wave-uniform)
+      cc[kr] = in ? dead : old;
+    }
+    if ((unsigned)lo > (unsigned)(63 - w)) {                                  // lo < 0 or lo + w > 63 (one pick of six): a neighbouring register too
+      asm volatile("");                                                       // the barriers keep these scalar branches (if-converted they become selects over the whole tuple)
+      if (lo < 0 && kr > 0) { asm volatile(""); const bool in = lane >= 64 + lo; const unsigned old = cc[kr - 1]; cc[kr - 1] = in ? dead : old; }
+      if (lo >= 0 && kr + 1 < K6) { asm volatile(""); const bool in = lane <= lo + w - 64; const unsigned old = cc[kr + 1]; cc[kr + 1] = in ? dead : old; }
+    }
+    if (P + 5 >= len) {                                                       // marks behind the sector: positions len .. P + fw
+      asm volatile("");
+      const int e = P + fw - (len - 1);
+      if (e > 0) spill |= (1u << e) - 1u;
+    }
+    return P;
+  };
+  // corners: largest curvature first (:291-344).  The reference's walk breaks at the 21st candidate before marking it (:312-315):
+  // nothing of that iteration survives, so the loop simply ends after the 20th pick.
+  int picks = 0;                                                              // lane q: local index of pick q
+  int count = 0;
+  for (; count < kLessSharpPerSector; ++count) {
+    unsigned m = cc[0];
+#pragma unroll
+    for (int r = 1; r < K6; ++r) m = cc[r] > m ? cc[r] : m;
+    int krl = 0;
+#pragma unroll
+    for (int r = 1; r < K6; ++r) krl = cc[r] == m ? r : krl;                  // the largest register holding the lane's maximum
+    const unsigned cmax = wave_reduce_u32<true>(m);
+    if (!(cmax - 1u >= kCurvThresholdBits && cmax - 1u <= kInfBits)) break;   // nothing alive (0 wraps) or nothing above 0.1 left
+    const unsigned long long tie = __ballot(m == cmax);
+    int f = __builtin_ctzll(tie);                                             // tie != 0: some lane holds the extreme
+    int kr = __builtin_amdgcn_readlane(krl, f);
+    if (__popcll(tie) != 1) {                                                 // equal curvatures in several lanes: the largest index
+      asm volatile("");
+      const unsigned w = wave_reduce_u32<true>(m == cmax ? (unsigned)(krl * 64 + lane) : 0u);
+      f = (int)(w & 63u); kr = (int)(w >> 6);
+    }
+    const int P = kill(kr, f, 0u);
+    picks = lane == count ? first + P : picks;
+  }
+  const int ncorner = count;
+  if (lane < ncorner) s_pick[j * kSlots + kSharpPerSector + lane] = (short)picks;
+  // flats: smallest curvature first (:346-390)
+#pragma unroll
+  for (int r = 0; r < K6; ++r) cc[r] -= 1u;                                   // curvature bits, 0xffffffff = dead
+  count = 0;
+  while (true) {
+    unsigned m = cc[0];
+#pragma unroll
+    for (int r = 1; r < K6; ++r) m = cc[r] < m ? cc[r] : m;
+    int krl = K6 - 1;
+#pragma unroll
+    for (int r = K6 - 2; r >= 0; --r) krl = cc[r] == m ? r : krl;             // the smallest register holding the lane's minimum
+    const unsigned cmin = wave_reduce_u32<false>(m);
+    if (!(cmin < kCurvThresholdBits)) break;                                  // nothing alive (0xffffffff) or nothing below 0.1 left
+    const unsigned long long tie = __ballot(m == cmin);
+    int f = __builtin_ctzll(tie);                                             // tie != 0: some lane holds the extreme
+    int kr = __builtin_amdgcn_readlane(krl, f);
+    if (__popcll(tie) != 1) {                                                 // ... the smallest index
+      asm volatile("");
+      const unsigned w = wave_reduce_u32<false>(m == cmin ? (unsigned)(krl * 64 + lane) : 0xffffffffu);
+      f = (int)(w & 63u); kr = (int)(w >> 6);
+    }
+    picks = lane == count ? first + kr * 64 + f : picks;
+    ++count;
+    if (count >= kFlatPerSector) break;                                       // 4th: break before marking (:359-362)
+    kill(kr, f, 0xffffffffu);
+  }
+  if (lane < count) s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + lane] = (short)picks;
+  if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
+}
+#else
 template <int K6>
 __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, int lane, const float* curv_l, const unsigned char* flags,
                                             short* s_pick, int* s_misc) {
@@ -422,6 +555,7 @@ __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, i
   }
   if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
 }
+#endif
 
 // ---- stable radix sort of the 32-bit run keys of a ring on their voxel-index bits ------------------------------------------------
 // key = voxel index << EB | first element; the keys are generated in element order, so a STABLE sort on the voxel bits alone gives
@@ -628,6 +762,15 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
   return n_vox;
 }
 
+#ifndef ALOAM_RF_PK_TILES
+#define ALOAM_RF_PK_TILES 1     // A/B builds: 0 = one float array per axis in the curvature tiles (round 2)
+#endif
+#ifndef ALOAM_RF_REACH_BITS
+#define ALOAM_RF_REACH_BITS 1   // A/B builds: 0 = gap flags as bytes, reach by walking them (round 2)
+#endif
+#ifndef ALOAM_RF_DPP_BOX
+#define ALOAM_RF_DPP_BOX 1      // A/B builds: 0 = voxel bounding box of a ring reduced with ds_bpermute shuffles (round 2)
+#endif
 template <int NPAD>
 __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int MAXN = NPAD + 11;
@@ -649,7 +792,15 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int A_BYTES = 8 * NPAD + 128;                                     // + room for the packed voxel cells behind the curvatures
   constexpr int TW = 256 + 10;                                                // a chunk of 256 points + 5 on either side
   static_assert(2 * 3 * TW * 4 <= A_BYTES && 4 * MAXN <= A_BYTES, "region A holds the curvature tiles and the curvature array");
+  // a tile keeps (x, y) as pairs and z apart: the 11-point sums run as packed f32 adds on the pairs a 64-bit LDS read delivers
+  // (one v_pk_add_f32 for x and y, the same IEEE additions in the same order) plus scalar adds for z
+  typedef float f2 __attribute__((ext_vector_type(2)));
+#if ALOAM_RF_PK_TILES
+  f2 (*txy)[TW] = reinterpret_cast<f2 (*)[TW]>(smem);
+  float (*tz)[TW] = reinterpret_cast<float (*)[TW]>(smem + 2 * TW * 8);
+#else
   float (*tile)[3][TW] = reinterpret_cast<float (*)[3][TW]>(smem);
+#endif
   // all scratch lives in the dynamic region so its base stays 16-byte aligned (no static __shared__ in front)
   constexpr int FLAG_BYTES = (MAXN + 15) & ~15;
   unsigned char* flags = smem + ((A_BYTES + 15) & ~15);
@@ -670,16 +821,35 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   static_assert(CELLS_OFF + 4 * MAXN <= A_BYTES, "the packed cells sit behind the curvature array in region A");
   unsigned* cells = reinterpret_cast<unsigned*>(smem + CELLS_OFF);
   const float inv = 1.0f / leaf;
-  if (tid == 0) s_misc[44] = 0;
+  // "the step s -> s + 1 is longer than the 0.05 threshold" as ONE BIT per step (bit s + 64 of gapw; steps that do not exist, s < 0
+  // and s >= n - 1, read 1): a wave ballots the 64 steps it has just computed, and the reach of the neighbour suppression around a
+  // point is two count-trailing-zeros on a 10-bit window of this array instead of up to ten dependent LDS byte reads.
+  unsigned long long* gapw = reinterpret_cast<unsigned long long*>(s_scan);
+  static_assert((ITEMS * 4 + 2) * 8 <= 256 * 4, "the gap bits fit the scan scratch");
+  if (tid == 0) { s_misc[44] = 0; if (ALOAM_RF_REACH_BITS) { gapw[0] = ~0ull; gapw[ITEMS * 4 + 1] = ~0ull; } }
   const float4* cloud = a.cloud + (long long)b * a.cap + start;
   // ---- curvature (:256-266) + gap flags, kept in registers until the tiles are retired.  The ring goes through LDS in chunks
   // of 256 points (thread tid owns point it * 256 + tid = tile column tid + 5); the next chunk is fetched while this one is used.
   const int L = n - 11;                          // E - S
   float cv[ITEMS];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#if ALOAM_RF_PK_TILES
   float4 pa = tid - 5 >= 0 && tid - 5 < n ? cloud[tid - 5] : zero4, pb = tid < 10 && tid + 251 < n ? cloud[tid + 251] : zero4;
+  // byte offsets of this thread's column in the two (x, y) tiles and the two z tiles, opaque to the compiler: every LDS read of the
+  // stencil is then base register + small immediate (folded into one constant, the second tile lies beyond the 8-bit offset range
+  // of ds_read2 and costs an address add per pair of reads)
+  unsigned oxy[2] = {(unsigned)tid * 8u, (unsigned)tid * 8u + TW * 8u}, oz[2] = {2u * TW * 8u + (unsigned)tid * 4u, 2u * TW * 8u + TW * 4u + (unsigned)tid * 4u};
+  asm volatile("" : "+v"(oxy[1]), "+v"(oz[0]), "+v"(oz[1]));
+#else
+  float4 pa = tid - 5 >= 0 && tid - 5 < n ? cloud[tid - 5] : zero4, pb = tid < 10 && tid + 251 < n ? cloud[tid + 251] : zero4;
+#endif
+#if ALOAM_RF_PK_TILES
+  txy[0][tid] = f2{pa.x, pa.y}; tz[0][tid] = pa.z;
+  if (tid < 10) { txy[0][tid + 256] = f2{pb.x, pb.y}; tz[0][tid + 256] = pb.z; }
+#else
   tile[0][0][tid] = pa.x; tile[0][1][tid] = pa.y; tile[0][2][tid] = pa.z;
   if (tid < 10) { tile[0][0][tid + 256] = pb.x; tile[0][1][tid + 256] = pb.y; tile[0][2][tid + 256] = pb.z; }
+#endif
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
@@ -691,14 +861,36 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       pb = tid < 10 && ib < n ? cloud[ib] : zero4;
     }
     cv[it] = 0.f;
+    bool gapf = true;
     if (i < n) {
+#if ALOAM_RF_PK_TILES
+      const f2* q = reinterpret_cast<const f2*>(smem + oxy[it & 1]) + 5;
+      const float* zs = reinterpret_cast<const float*>(smem + oz[it & 1]) + 5;
+      const f2 q0 = q[0];
+      const float z0 = zs[0];
+      if (i < n - 1) {
+        const f2 d = q[1] - q0, dd = d * d;
+        const float dz = zs[1] - z0;
+        gapf = (double)(dd.x + dd.y + dz * dz) > 0.05;                         // :324 etc.
+      }
+      if (i >= 5 && i < n - 5) {
+        f2 sxy = q[-5] + q[-4]; sxy = sxy + q[-3]; sxy = sxy + q[-2]; sxy = sxy + q[-1]; sxy = sxy - 10.f * q0;
+        sxy = sxy + q[1]; sxy = sxy + q[2]; sxy = sxy + q[3]; sxy = sxy + q[4]; sxy = sxy + q[5];
+        const float dZ = zs[-5] + zs[-4] + zs[-3] + zs[-2] + zs[-1] - 10 * z0 + zs[1] + zs[2] + zs[3] + zs[4] + zs[5];
+        const f2 ss = sxy * sxy;
+        cv[it] = ss.x + ss.y + dZ * dZ;
+        if (a.store_debug) a.curv[(long long)b * a.cap + start + i] = cv[it];
+      }
+      label[i] = 0;
+      const f2 cxy = q0 * inv;
+      const float fx = floorf(cxy.x), fy = floorf(cxy.y), fz = floorf(z0 * inv);
+#else
       const float* xs = tile[it & 1][0] + tid + 5;
       const float* ys = tile[it & 1][1] + tid + 5;
       const float* zs = tile[it & 1][2] + tid + 5;
-      unsigned char f = 0;
       if (i < n - 1) {
         const float dx = xs[1] - xs[0], dy = ys[1] - ys[0], dz = zs[1] - zs[0];
-        if ((double)(dx * dx + dy * dy + dz * dz) > 0.05) f = 2;              // :324 etc.
+        gapf = (double)(dx * dx + dy * dy + dz * dz) > 0.05;                   // :324 etc.
       }
       if (i >= 5 && i < n - 5) {
         const float dX = xs[-5] + xs[-4] + xs[-3] + xs[-2] + xs[-1] - 10 * xs[0] + xs[1] + xs[2] + xs[3] + xs[4] + xs[5];
@@ -707,43 +899,74 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
         cv[it] = dX * dX + dY * dY + dZ * dZ;
         if (a.store_debug) a.curv[(long long)b * a.cap + start + i] = cv[it];
       }
-      flags[i] = f;
       label[i] = 0;
       const float fx = floorf(xs[0] * inv), fy = floorf(ys[0] * inv), fz = floorf(zs[0] * inv);
+#endif
+      if (!ALOAM_RF_REACH_BITS) flags[i] = (unsigned char)(i < n - 1 && gapf ? 2 : 0);
       const bool okc = fabsf(fx) < 1024.f && fabsf(fy) < 1024.f && fabsf(fz) < 512.f;
       if (!okc) s_misc[44] = 1;
       cells[i] = okc ? (unsigned)((int)fx + 1024) | ((unsigned)((int)fy + 1024) << 11) | ((unsigned)((int)fz + 512) << 22) : 0u;
     }
+    if (ALOAM_RF_REACH_BITS) {
+      const unsigned long long gb = __ballot(gapf);                            // steps it * 256 + wave * 64 .. + 63
+      if (lane == 0) gapw[1 + it * 4 + wave] = gb;
+    }
     if (more) {
       const int nb = (it + 1) & 1;
+#if ALOAM_RF_PK_TILES
+      txy[nb][tid] = f2{pa.x, pa.y}; tz[nb][tid] = pa.z;
+      if (tid < 10) { txy[nb][tid + 256] = f2{pb.x, pb.y}; tz[nb][tid + 256] = pb.z; }
+#else
       tile[nb][0][tid] = pa.x; tile[nb][1][tid] = pa.y; tile[nb][2][tid] = pa.z;
       if (tid < 10) { tile[nb][0][tid + 256] = pb.x; tile[nb][1][tid + 256] = pb.y; tile[nb][2][tid + 256] = pb.z; }
+#endif
     }
     __syncthreads();
   }
 
   RF_T(1);   // curvature
   // reach of the neighbour suppression around every point: a pick of i marks i+1 .. i+fw and i-1 .. i-bk (runs of consecutive
-  // gap-free steps, at most 5).  Packed into the flag byte: bit1 gap, bits 2-4 fw, bits 5-7 bk.
-  unsigned char rb[ITEMS];
+  // gap-free steps, at most 5; :316-341).  Packed into the flag byte: bits 2-4 fw, bits 5-7 bk.  The curvature tiles are retired
+  // (the loop above ends with a barrier), so region A takes the curvature per local point in the same pass.
+  float* curv_l = reinterpret_cast<float*>(smem);
+#if !ALOAM_RF_REACH_BITS
+  {
+    unsigned char rb[ITEMS];
 #pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int i = tid + it * 256;
-    rb[it] = 0;
-    if (i < n) {
-      int fw = 0, bk = 0;
-      while (fw < 5 && i + fw < n - 1 && !(flags[i + fw] & 2)) ++fw;
-      while (bk < 5 && i - 1 - bk >= 0 && !(flags[i - 1 - bk] & 2)) ++bk;
-      rb[it] = (unsigned char)((fw << 2) | (bk << 5));
+    for (int it = 0; it < ITEMS; ++it) {
+      const int i = tid + it * 256;
+      rb[it] = 0;
+      if (i < n) {
+        int fw = 0, bk = 0;
+        while (fw < 5 && i + fw < n - 1 && !(flags[i + fw] & 2)) ++fw;
+        while (bk < 5 && i - 1 - bk >= 0 && !(flags[i - 1 - bk] & 2)) ++bk;
+        rb[it] = (unsigned char)((fw << 2) | (bk << 5));
+      }
+    }
+    __syncthreads();                                                         // gap bytes fully consumed
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+      const int i = tid + it * 256;
+      if (i < n) { curv_l[i] = cv[it]; flags[i] = rb[it]; }
     }
   }
-  __syncthreads();                                                           // tile and gap bits fully consumed
-  float* curv_l = reinterpret_cast<float*>(smem);                             // region A again: curvature per local point
+#else
+  {
+    const unsigned* gw32 = reinterpret_cast<const unsigned*>(gapw);
 #pragma unroll
-  for (int it = 0; it < ITEMS; ++it) {
-    const int i = tid + it * 256;
-    if (i < n) { curv_l[i] = cv[it]; flags[i] = (unsigned char)(flags[i] | rb[it]); }
+    for (int it = 0; it < ITEMS; ++it) {
+      const int i = tid + it * 256;
+      if (i < n) {
+        const unsigned bit = (unsigned)i + 59u;                                // bit of step i - 5
+        const unsigned win = __builtin_amdgcn_alignbit(gw32[(bit >> 5) + 1], gw32[bit >> 5], bit & 31u);   // bits 0 .. 9: steps i - 5 .. i + 4
+        const int fw = __builtin_ctz((win >> 5) | 32u);                        // steps i, i + 1, ...
+        const int bk = __builtin_ctz(__builtin_bitreverse32(win << 27) | 32u); // steps i - 1, i - 2, ...
+        curv_l[i] = cv[it];
+        flags[i] = (unsigned char)((fw << 2) | (bk << 5));
+      }
+    }
   }
+#endif
   __syncthreads();
 
   RF_T(2);   // reach + curvature array
@@ -751,11 +974,13 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // sectors leave on its first five points; those marks only matter if the sector picked one of the marked points, which
   // the second pass detects (and then redoes that sector with the marks) in sector order
   constexpr int K6 = (NPAD / 6 + 2 + 63) / 64;
-  for (int j = wave; j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);
+#pragma unroll 1
+  for (int j = __builtin_amdgcn_readfirstlane(wave); j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);   // j in an SGPR: sector bounds, pick positions and spill marks are scalar work
   __syncthreads();
   RF_T(3);   // first-pass selection
   if (wave == 0) {
     unsigned carry = (unsigned)s_misc[8];                                    // marks on the (up to 5) points after sector 0
+#pragma unroll 1
     for (int j = 1; j < kSectors; ++j) {
       const int sp = (L * j) / 6, len = (L * (j + 1)) / 6 - sp;
       const unsigned m = len >= 5 ? carry : (carry & ((1u << len) - 1u));    // marks that fall inside this sector
@@ -827,8 +1052,13 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       }
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < 3; ++q) {                                            // DPP ladders (signed order = unsigned order of x ^ 0x80000000)
+#if ALOAM_RF_DPP_BOX
+      mn[q] = (int)(wave_reduce_u32<false>((unsigned)mn[q] ^ 0x80000000u) ^ 0x80000000u);
+      mx[q] = (int)(wave_reduce_u32<true>((unsigned)mx[q] ^ 0x80000000u) ^ 0x80000000u);
+#else
       for (int d = 32; d > 0; d >>= 1) { mn[q] = min(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = max(mx[q], __shfl_down(mx[q], d, 64)); }
+#endif
       if (lane == 0) { s_redi[q][wave] = mn[q]; s_redi[3 + q][wave] = mx[q]; }
     }
     __syncthreads();

@@ -91,7 +91,70 @@ def pick_sector(j, init_marks, L, curv, reach):
     return corners, flats, spill
 
 
-def model(curv, gap, n):
+THR = int(np.float32(0.1).view(np.uint32))           # kCurvThresholdBits
+INF = 0x7f800000
+
+
+def pick_sector_regs(j, init_marks, L, curv, reach, W=64, spare=1):
+    """pick_sector as the kernel evaluates it since round 3 (ALOAM_RF_PICK 2): point `pos` of the sector in register pos // W of lane
+    pos % W; "dead" folded into the key (corner walk: curvature bits + 1, 0 = dead; flat walk: curvature bits, 0xffffffff = dead); the
+    0.1 thresholds as integer compares on the bits; a pick kills through lane ranges of register kr and, when the range leaves
+    0 .. W-1, of the register before or behind; the corner walk ends after the 20th pick.  W = 16 or 32 instead of 64 makes the
+    register borders frequent."""
+    sp, ln = (L * j) // 6, (L * (j + 1)) // 6 - (L * j) // 6
+    first = sp + 5
+    K = (ln + W - 1) // W + spare
+    M32 = 0xffffffff
+    cc = np.zeros((K, W), np.int64)
+    for pos in range(ln):
+        if not (pos < 5 and (init_marks >> pos) & 1):
+            cc[pos // W, pos % W] = int(np.float32(curv[first + pos]).view(np.uint32)) + 1
+    spill = 0
+    lanes = np.arange(W)
+    def kill(kr, f, dead):
+        nonlocal spill
+        fw, bk = reach[first + kr * W + f]
+        P, lo, w = kr * W + f, f - bk, fw + bk
+        cc[kr, ((lanes - lo) & M32) <= w] = dead
+        if (lo & M32) > ((W - 1 - w) & M32):
+            if lo < 0 and kr > 0: cc[kr - 1, lanes >= W + lo] = dead
+            if lo >= 0 and kr + 1 < K: cc[kr + 1, lanes <= lo + w - W] = dead
+        if P + 5 >= ln:
+            e = P + fw - (ln - 1)
+            if e > 0: spill |= (1 << e) - 1
+        return P
+    corners, flats = [], []
+    for count in range(20):
+        m = cc.max(axis=0)
+        krl = np.zeros(W, np.int64)
+        for r in range(1, K): krl = np.where(cc[r] == m, r, krl)
+        cmax = int(m.max())
+        if not (THR <= ((cmax - 1) & M32) <= INF): break
+        tie = np.flatnonzero(m == cmax)
+        f = int(tie[0]); kr = int(krl[f])
+        if len(tie) != 1:
+            wv = int(np.where(m == cmax, krl * W + lanes, 0).max()); f, kr = wv % W, wv // W
+        corners.append(first + kill(kr, f, 0))
+    cc = (cc - 1) & M32
+    count = 0
+    while True:
+        m = cc.min(axis=0)
+        krl = np.full(W, K - 1, np.int64)
+        for r in range(K - 2, -1, -1): krl = np.where(cc[r] == m, r, krl)
+        cmin = int(m.min())
+        if not cmin < THR: break
+        tie = np.flatnonzero(m == cmin)
+        f = int(tie[0]); kr = int(krl[f])
+        if len(tie) != 1:
+            wv = int(np.where(m == cmin, krl * W + lanes, M32).min()); f, kr = wv % W, wv // W
+        flats.append(first + kr * W + f)
+        count += 1
+        if count >= 4: break
+        kill(kr, f, M32)
+    return corners, flats, spill
+
+
+def model(curv, gap, n, pick_sector=pick_sector):
     L = n - 11
     reach = []
     for i in range(n):
@@ -131,3 +194,33 @@ def test_speculative_sector_selection_equals_the_sequential_walk(seed):
         la, pa = literal(curv, gap, n)
         lb, pb = model(curv, gap, n)
         assert np.array_equal(la, lb) and pa == pb, (seed, trial, n, curv.tolist(), gap.tolist(), pa, pb)
+
+
+@pytest.mark.parametrize("W", [16, 32, 64])
+def test_register_level_selection_equals_the_sequential_walk(W):
+    """The loop the kernel runs (keys with "dead" folded in, integer thresholds, lane-range kills through register kr and its
+    neighbours) against the reference's literal walk, with register borders every 16 / 32 / 64 points."""
+    rng = np.random.default_rng(700 + W)
+    sizes = [17, 23, 41, 90, 150, 400, 700] if W < 64 else [41, 150, 400, 900, 2059]
+    for trial in range(120 if W < 64 else 40):
+        n = int(rng.choice(sizes))
+        style = trial % 4
+        if style == 0:   curv = rng.exponential(0.2, n)
+        elif style == 1: curv = rng.choice([0.0, 0.05, 0.1, 0.2, 1.0], n)
+        elif style == 2: curv = np.where(rng.random(n) < 0.5, rng.uniform(0.11, 3, n), rng.uniform(0, 0.09, n))
+        else:            curv = np.round(rng.exponential(0.3, n), 1)
+        curv = curv.astype(np.float32)
+        gap = rng.random(n) < rng.choice([0.0, 0.05, 0.3, 0.8])
+        la, pa = literal(curv, gap, n)
+        lb, pb = model(curv, gap, n, lambda *a: pick_sector_regs(*a, W=W, spare=trial % 2))
+        assert np.array_equal(la, lb) and pa == pb, (W, trial, n)
+
+
+def test_curvature_thresholds_as_integer_compares():
+    """`(double)c > 0.1` == `THR <= bits(c) <= bits(inf)` and `(double)c < 0.1` == `bits(c) < THR` for every non-negative float."""
+    rng = np.random.default_rng(5)
+    bits = np.concatenate([np.arange(THR - 4096, THR + 4096), rng.integers(0, 0x7f800000, 200000), [0, 1, INF - 1, INF, INF + 1, 0x7fc00000, 0x7fffffff]]).astype(np.uint32)
+    with np.errstate(invalid="ignore"):
+        c = bits.view(np.float32).astype(np.float64)
+        assert np.array_equal(c > 0.1, (bits >= THR) & (bits <= INF))
+        assert np.array_equal(c < 0.1, bits < THR)
