@@ -355,12 +355,10 @@ __device__ __forceinline__ int gather_counts(const unsigned long long* slots, in
 //     register tuple that is indexed through the VGPR index mode (s_set_gpr_idx_on), one compare and one select per touched register
 //     (the neighbours only when the reach leaves lanes 0 .. 63, one pick of six);
 //   * the picks collect in one VGPR (lane = pick number) and go to LDS once.
-#ifndef ALOAM_RF_PICK
-#define ALOAM_RF_PICK 2         // A/B builds: 1 = the round-2 loop (alive bit mask, curvature compared as double)
-#endif
-constexpr unsigned kCurvThresholdBits = 0x3DCCCCCDu;                          // bits(0.1f); tests/host/test_trig_port.cpp checks the claim above
+// Measured (A/B on one box, batch 1024, profiles/r03_ab_ring_features.md): ~58 VALU + ~55 SALU per pick before, ~32 + ~36 now; together
+// with the bit-mask reach and the packed curvature tiles below the kernel went from 2.95 to 2.43 ms, SQ_INSTS_VALU from 1322 M to 981 M.
+constexpr unsigned kCurvThresholdBits = 0x3DCCCCCDu;                          // bits(0.1f); tests/test_selection_model.py checks the claim above
 constexpr unsigned kInfBits = 0x7f800000u;
-#if ALOAM_RF_PICK == 2
 template <int K6>
 __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, int lane, const float* curv_l, const unsigned char* flags,
                                             short* s_pick, int* s_misc) {
@@ -474,88 +472,6 @@ __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, i
   if (lane < count) s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + lane] = (short)picks;
   if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
 }
-#else
-template <int K6>
-__device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, int lane, const float* curv_l, const unsigned char* flags,
-                                            short* s_pick, int* s_misc) {
-  constexpr int kSlots = kSharpPerSector + kLessSharpPerSector + kFlatPerSector;
-  constexpr int NRP = (K6 + 4) / 5;                                           // reach bytes packed 5 x 6 bit per register
-  const int sp = (L * j) / 6, len = (L * (j + 1)) / 6 - sp;
-  const int first = sp + 5, last = sp + len - 1 + 5;                          // local indices of the sector's first / last point
-  unsigned cb[K6];                                                            // curvature bits (non-negative floats order like integers)
-  unsigned rp[NRP];
-  unsigned alive = 0;
-#pragma unroll
-  for (int q = 0; q < NRP; ++q) rp[q] = 0;
-#pragma unroll
-  for (int r = 0; r < K6; ++r) {
-    const int pos = r * 64 + lane;
-    cb[r] = 0u;
-    if (pos < len) {
-      const int i = first + pos;
-      cb[r] = __float_as_uint(curv_l[i]);
-      rp[r / 5] |= (unsigned)(flags[i] >> 2) << (6 * (r % 5));
-      if (!(pos < 5 && ((init_marks >> pos) & 1u))) alive |= 1u << r;
-    }
-  }
-  unsigned spill = 0;
-  // a pick at register kr of lane f: (fw, bk) = reach of the picked point; returns its local index
-  auto pick_at = [&](int kr, int f) {
-    unsigned rpk = 0;
-#pragma unroll
-    for (int q = 0; q < NRP; ++q) { const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)rp[q], f); if (q == kr / 5) rpk = x; }
-    const unsigned rb = (rpk >> (6 * (kr % 5))) & 63u;
-    const int fw = (int)(rb & 7u), bk = (int)(rb >> 3);
-    const int dl = lane - f;
-    unsigned kill = 0;
-    if (dl >= -bk && dl <= fw) kill |= 1u << kr;
-    if (dl + 64 >= 1 && dl + 64 <= fw) kill |= (1u << kr) << 1;
-    if (dl - 64 <= -1 && dl - 64 >= -bk) kill |= (1u << kr) >> 1;
-    alive &= ~kill;
-    const int kf = first + kr * 64 + f;
-    if (kf + fw > last) for (int off = 1; off <= fw; ++off) if (kf + off > last) spill |= 1u << (kf + off - last - 1);   // marks behind the sector
-    return kf;
-  };
-  // corners: largest curvature first (:291-344)
-  int count = 0;
-  while (true) {
-    unsigned bc = 0u;
-    int br = 0;
-#pragma unroll
-    for (int r = 0; r < K6; ++r) if (((alive >> r) & 1u) && cb[r] >= bc && cb[r] != 0u) { bc = cb[r]; br = r; }
-    const unsigned cmax = wave_extreme_u32<true>(bc, lane);
-    if (cmax == 0u || !((double)__uint_as_float(cmax) > 0.1)) break;         // nothing left that is a corner candidate
-    ++count;
-    if (count > kLessSharpPerSector) break;                                   // 21st: break before marking (:312-315)
-    const unsigned long long tie = __ballot(bc == cmax);
-    int f, kr;
-    if (__popcll(tie) == 1) { f = __ffsll((long long)tie) - 1; kr = __builtin_amdgcn_readlane(br, f); }
-    else { const unsigned w = wave_extreme_u32<true>(bc == cmax ? (unsigned)(br * 64 + lane) : 0u, lane); f = (int)(w & 63u); kr = (int)(w >> 6); }
-    const int kf = pick_at(kr, f);
-    if (lane == 0) s_pick[j * kSlots + kSharpPerSector + count - 1] = (short)kf;
-  }
-  const int ncorner = count > kLessSharpPerSector ? kLessSharpPerSector : count;
-  // flats: smallest curvature first (:346-390)
-  count = 0;
-  while (true) {
-    unsigned bc = 0xffffffffu;
-    int br = 0;
-#pragma unroll
-    for (int r = 0; r < K6; ++r) if (((alive >> r) & 1u) && cb[r] < bc) { bc = cb[r]; br = r; }
-    const unsigned cmin = wave_extreme_u32<false>(bc, lane);
-    if (cmin == 0xffffffffu || !((double)__uint_as_float(cmin) < 0.1)) break;
-    const unsigned long long tie = __ballot(bc == cmin);
-    int f, kr;
-    if (__popcll(tie) == 1) { f = __ffsll((long long)tie) - 1; kr = __builtin_amdgcn_readlane(br, f); }
-    else { const unsigned w = wave_extreme_u32<false>(bc == cmin ? (unsigned)(br * 64 + lane) : 0xffffffffu, lane); f = (int)(w & 63u); kr = (int)(w >> 6); }
-    if (lane == 0) s_pick[j * kSlots + kSharpPerSector + kLessSharpPerSector + count] = (short)(first + kr * 64 + f);
-    ++count;
-    if (count >= kFlatPerSector) break;                                       // 4th: break before marking (:359-362)
-    pick_at(kr, f);
-  }
-  if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
-}
-#endif
 
 // ---- stable radix sort of the 32-bit run keys of a ring on their voxel-index bits ------------------------------------------------
 // key = voxel index << EB | first element; the keys are generated in element order, so a STABLE sort on the voxel bits alone gives
@@ -762,15 +678,6 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
   return n_vox;
 }
 
-#ifndef ALOAM_RF_PK_TILES
-#define ALOAM_RF_PK_TILES 1     // A/B builds: 0 = one float array per axis in the curvature tiles (round 2)
-#endif
-#ifndef ALOAM_RF_REACH_BITS
-#define ALOAM_RF_REACH_BITS 1   // A/B builds: 0 = gap flags as bytes, reach by walking them (round 2)
-#endif
-#ifndef ALOAM_RF_DPP_BOX
-#define ALOAM_RF_DPP_BOX 1      // A/B builds: 0 = voxel bounding box of a ring reduced with ds_bpermute shuffles (round 2)
-#endif
 template <int NPAD>
 __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int MAXN = NPAD + 11;
@@ -795,12 +702,8 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // a tile keeps (x, y) as pairs and z apart: the 11-point sums run as packed f32 adds on the pairs a 64-bit LDS read delivers
   // (one v_pk_add_f32 for x and y, the same IEEE additions in the same order) plus scalar adds for z
   typedef float f2 __attribute__((ext_vector_type(2)));
-#if ALOAM_RF_PK_TILES
   f2 (*txy)[TW] = reinterpret_cast<f2 (*)[TW]>(smem);
   float (*tz)[TW] = reinterpret_cast<float (*)[TW]>(smem + 2 * TW * 8);
-#else
-  float (*tile)[3][TW] = reinterpret_cast<float (*)[3][TW]>(smem);
-#endif
   // all scratch lives in the dynamic region so its base stays 16-byte aligned (no static __shared__ in front)
   constexpr int FLAG_BYTES = (MAXN + 15) & ~15;
   unsigned char* flags = smem + ((A_BYTES + 15) & ~15);
@@ -826,30 +729,21 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // point is two count-trailing-zeros on a 10-bit window of this array instead of up to ten dependent LDS byte reads.
   unsigned long long* gapw = reinterpret_cast<unsigned long long*>(s_scan);
   static_assert((ITEMS * 4 + 2) * 8 <= 256 * 4, "the gap bits fit the scan scratch");
-  if (tid == 0) { s_misc[44] = 0; if (ALOAM_RF_REACH_BITS) { gapw[0] = ~0ull; gapw[ITEMS * 4 + 1] = ~0ull; } }
+  if (tid == 0) { s_misc[44] = 0; gapw[0] = ~0ull; gapw[ITEMS * 4 + 1] = ~0ull; }
   const float4* cloud = a.cloud + (long long)b * a.cap + start;
   // ---- curvature (:256-266) + gap flags, kept in registers until the tiles are retired.  The ring goes through LDS in chunks
   // of 256 points (thread tid owns point it * 256 + tid = tile column tid + 5); the next chunk is fetched while this one is used.
   const int L = n - 11;                          // E - S
   float cv[ITEMS];
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#if ALOAM_RF_PK_TILES
   float4 pa = tid - 5 >= 0 && tid - 5 < n ? cloud[tid - 5] : zero4, pb = tid < 10 && tid + 251 < n ? cloud[tid + 251] : zero4;
   // byte offsets of this thread's column in the two (x, y) tiles and the two z tiles, opaque to the compiler: every LDS read of the
   // stencil is then base register + small immediate (folded into one constant, the second tile lies beyond the 8-bit offset range
   // of ds_read2 and costs an address add per pair of reads)
   unsigned oxy[2] = {(unsigned)tid * 8u, (unsigned)tid * 8u + TW * 8u}, oz[2] = {2u * TW * 8u + (unsigned)tid * 4u, 2u * TW * 8u + TW * 4u + (unsigned)tid * 4u};
   asm volatile("" : "+v"(oxy[1]), "+v"(oz[0]), "+v"(oz[1]));
-#else
-  float4 pa = tid - 5 >= 0 && tid - 5 < n ? cloud[tid - 5] : zero4, pb = tid < 10 && tid + 251 < n ? cloud[tid + 251] : zero4;
-#endif
-#if ALOAM_RF_PK_TILES
   txy[0][tid] = f2{pa.x, pa.y}; tz[0][tid] = pa.z;
   if (tid < 10) { txy[0][tid + 256] = f2{pb.x, pb.y}; tz[0][tid + 256] = pb.z; }
-#else
-  tile[0][0][tid] = pa.x; tile[0][1][tid] = pa.y; tile[0][2][tid] = pa.z;
-  if (tid < 10) { tile[0][0][tid + 256] = pb.x; tile[0][1][tid + 256] = pb.y; tile[0][2][tid + 256] = pb.z; }
-#endif
   __syncthreads();
 #pragma unroll
   for (int it = 0; it < ITEMS; ++it) {
@@ -863,7 +757,6 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     cv[it] = 0.f;
     bool gapf = true;
     if (i < n) {
-#if ALOAM_RF_PK_TILES
       const f2* q = reinterpret_cast<const f2*>(smem + oxy[it & 1]) + 5;
       const float* zs = reinterpret_cast<const float*>(smem + oz[it & 1]) + 5;
       const f2 q0 = q[0];
@@ -884,42 +777,18 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       label[i] = 0;
       const f2 cxy = q0 * inv;
       const float fx = floorf(cxy.x), fy = floorf(cxy.y), fz = floorf(z0 * inv);
-#else
-      const float* xs = tile[it & 1][0] + tid + 5;
-      const float* ys = tile[it & 1][1] + tid + 5;
-      const float* zs = tile[it & 1][2] + tid + 5;
-      if (i < n - 1) {
-        const float dx = xs[1] - xs[0], dy = ys[1] - ys[0], dz = zs[1] - zs[0];
-        gapf = (double)(dx * dx + dy * dy + dz * dz) > 0.05;                   // :324 etc.
-      }
-      if (i >= 5 && i < n - 5) {
-        const float dX = xs[-5] + xs[-4] + xs[-3] + xs[-2] + xs[-1] - 10 * xs[0] + xs[1] + xs[2] + xs[3] + xs[4] + xs[5];
-        const float dY = ys[-5] + ys[-4] + ys[-3] + ys[-2] + ys[-1] - 10 * ys[0] + ys[1] + ys[2] + ys[3] + ys[4] + ys[5];
-        const float dZ = zs[-5] + zs[-4] + zs[-3] + zs[-2] + zs[-1] - 10 * zs[0] + zs[1] + zs[2] + zs[3] + zs[4] + zs[5];
-        cv[it] = dX * dX + dY * dY + dZ * dZ;
-        if (a.store_debug) a.curv[(long long)b * a.cap + start + i] = cv[it];
-      }
-      label[i] = 0;
-      const float fx = floorf(xs[0] * inv), fy = floorf(ys[0] * inv), fz = floorf(zs[0] * inv);
-#endif
-      if (!ALOAM_RF_REACH_BITS) flags[i] = (unsigned char)(i < n - 1 && gapf ? 2 : 0);
       const bool okc = fabsf(fx) < 1024.f && fabsf(fy) < 1024.f && fabsf(fz) < 512.f;
       if (!okc) s_misc[44] = 1;
       cells[i] = okc ? (unsigned)((int)fx + 1024) | ((unsigned)((int)fy + 1024) << 11) | ((unsigned)((int)fz + 512) << 22) : 0u;
     }
-    if (ALOAM_RF_REACH_BITS) {
+    {
       const unsigned long long gb = __ballot(gapf);                            // steps it * 256 + wave * 64 .. + 63
       if (lane == 0) gapw[1 + it * 4 + wave] = gb;
     }
     if (more) {
       const int nb = (it + 1) & 1;
-#if ALOAM_RF_PK_TILES
       txy[nb][tid] = f2{pa.x, pa.y}; tz[nb][tid] = pa.z;
       if (tid < 10) { txy[nb][tid + 256] = f2{pb.x, pb.y}; tz[nb][tid + 256] = pb.z; }
-#else
-      tile[nb][0][tid] = pa.x; tile[nb][1][tid] = pa.y; tile[nb][2][tid] = pa.z;
-      if (tid < 10) { tile[nb][0][tid + 256] = pb.x; tile[nb][1][tid + 256] = pb.y; tile[nb][2][tid + 256] = pb.z; }
-#endif
     }
     __syncthreads();
   }
@@ -929,28 +798,6 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // gap-free steps, at most 5; :316-341).  Packed into the flag byte: bits 2-4 fw, bits 5-7 bk.  The curvature tiles are retired
   // (the loop above ends with a barrier), so region A takes the curvature per local point in the same pass.
   float* curv_l = reinterpret_cast<float*>(smem);
-#if !ALOAM_RF_REACH_BITS
-  {
-    unsigned char rb[ITEMS];
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int i = tid + it * 256;
-      rb[it] = 0;
-      if (i < n) {
-        int fw = 0, bk = 0;
-        while (fw < 5 && i + fw < n - 1 && !(flags[i + fw] & 2)) ++fw;
-        while (bk < 5 && i - 1 - bk >= 0 && !(flags[i - 1 - bk] & 2)) ++bk;
-        rb[it] = (unsigned char)((fw << 2) | (bk << 5));
-      }
-    }
-    __syncthreads();                                                         // gap bytes fully consumed
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-      const int i = tid + it * 256;
-      if (i < n) { curv_l[i] = cv[it]; flags[i] = rb[it]; }
-    }
-  }
-#else
   {
     const unsigned* gw32 = reinterpret_cast<const unsigned*>(gapw);
 #pragma unroll
@@ -966,7 +813,6 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       }
     }
   }
-#endif
   __syncthreads();
 
   RF_T(2);   // reach + curvature array
@@ -1053,12 +899,8 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {                                            // DPP ladders (signed order = unsigned order of x ^ 0x80000000)
-#if ALOAM_RF_DPP_BOX
       mn[q] = (int)(wave_reduce_u32<false>((unsigned)mn[q] ^ 0x80000000u) ^ 0x80000000u);
       mx[q] = (int)(wave_reduce_u32<true>((unsigned)mx[q] ^ 0x80000000u) ^ 0x80000000u);
-#else
-      for (int d = 32; d > 0; d >>= 1) { mn[q] = min(mn[q], __shfl_down(mn[q], d, 64)); mx[q] = max(mx[q], __shfl_down(mx[q], d, 64)); }
-#endif
       if (lane == 0) { s_redi[q][wave] = mn[q]; s_redi[3 + q][wave] = mx[q]; }
     }
     __syncthreads();
