@@ -224,3 +224,30 @@ def test_curvature_thresholds_as_integer_compares():
         c = bits.view(np.float32).astype(np.float64)
         assert np.array_equal(c > 0.1, (bits >= THR) & (bits <= INF))
         assert np.array_equal(c < 0.1, bits < THR)
+
+
+def test_reach_from_the_gap_bit_window():
+    """k_ring_features keeps "step s -> s + 1 is longer than the threshold" as one bit per step (bit s + 64 of an array whose first
+    word and whose steps >= n - 1 read 1) and takes the reach of the neighbour suppression around point i from the 10-bit window
+    of steps i - 5 .. i + 4: fw = ctz(window >> 5 | 32), bk = ctz(bitreverse(window << 27) | 32).  Against the literal loops
+    (reference src/scanRegistration.cpp:316-341: stop at the first long step, at most 5, inside the ring)."""
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        n = int(rng.integers(1, 700))
+        gap = rng.random(n) < rng.choice([0.0, 0.1, 0.5, 0.9, 1.0])
+        padded = ((n + 255) // 256) * 256                                  # the kernel ballots whole chunks of 256 steps
+        bits = np.ones(64 + padded + 64, np.uint8)
+        bits[64:64 + n - 1] = gap[:n - 1]                                  # steps 0 .. n - 2 exist
+        words = np.packbits(bits, bitorder="little").view(np.uint32)
+        for i in range(n):
+            bit = i + 59
+            lo, hi = int(words[bit >> 5]), int(words[(bit >> 5) + 1])
+            win = (((hi << 32) | lo) >> (bit & 31)) & 0xffffffff           # v_alignbit_b32
+            ctz = lambda x: (x & -x).bit_length() - 1
+            brev = lambda x: int(format(x & 0xffffffff, "032b")[::-1], 2)
+            fw = ctz((win >> 5) | 32)
+            bk = ctz(brev((win << 27) & 0xffffffff) | 32)
+            fw_ref = bk_ref = 0
+            while fw_ref < 5 and i + fw_ref < n - 1 and not gap[i + fw_ref]: fw_ref += 1
+            while bk_ref < 5 and i - 1 - bk_ref >= 0 and not gap[i - 1 - bk_ref]: bk_ref += 1
+            assert (fw, bk) == (fw_ref, bk_ref), (trial, n, i)

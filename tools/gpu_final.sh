@@ -1,7 +1,8 @@
 #!/bin/bash
 # tools/gpu_final.sh <tag> — one call on the GPU box, most important first (the call may be cut short by the GPU-minute budget):
-#   1. parity suite (-m gpu) with the product library; if it fails, the A/B builds in a-loam_amd/lib/variants (one k_ring_features
-#      change switched off each, see tools/build_variant.sh) are tried on the registration subset to name the change that breaks it
+#   1. parity suite (-m gpu) with the product library; if it fails, whatever A/B builds sit in a-loam_amd/lib/variants (built with
+#      tools/build_variant.sh, e.g. one change switched off each; names below) are tried on the registration subset to name the change
+#      that breaks it, and the first that passes is the library the rest of the script measures
 #   2. A/B of k_ring_features: the product library against the build of the previous commit (variants/libold.so), same box
 #   3. rocprofv3 kernel stats of the headline workload, SQ instruction counters of k_ring_features
 #   4. the default bench line
