@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""A/B of two builds of the library on the GPU box WITHOUT torch and pytest: same sweeps through both, every output compared bit
+for bit, per-kernel hipEvent times side by side.  A call costs ~20-30 s of box time (python + numpy + ctypes start in a second;
+`import torch` alone takes a minute on a fresh box), so a kernel experiment can be answered ten times as often as with
+tools/gpu_variants.sh; the full parity suite still decides what ships.
+
+    # here (CPU, torch available): sweeps of a few distinct synthetic sequences -> tools/_ab_inputs.npz (git-ignored, travels with gpurun)
+    python tools/ab_check.py make-inputs [--sensor HDL-64] [--frames 3] [--sequences 4]
+    # on the GPU box, e.g.  gpurun --timeout 60 -- 'python tools/ab_check.py ab product a-loam_amd/lib/variants/libX.so'
+    python tools/ab_check.py run <lib | product> <out.npz> [--batch 1024] [--steps 12] [--mapping]
+    python tools/ab_check.py compare <a.npz> <b.npz>
+    python tools/ab_check.py ab <lib a> <lib b> [run options]        # run + run + compare, each run in its own process
+
+The batch is filled by replicating the stored sequences over device memory (distinct addresses, so caches see a real batch; sequence
+b replays stored sequence b mod S).  What is compared: the four feature clouds and CORNER_LAST / SURF_LAST of three sequences after
+every step, poses and solver statistics of those sequences after every step, (with --mapping) the refined poses and map sizes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+INPUTS = os.path.join(ROOT, "tools", "_ab_inputs.npz")
+
+
+def opt(argv, name, default, cast=int):
+    return cast(argv[argv.index(name) + 1]) if name in argv else default
+
+
+def make_inputs(argv):
+    syn = importlib.import_module("a-loam_amd.synthetic")
+    sensor, T, S = opt(argv, "--sensor", "HDL-64", str), opt(argv, "--frames", 3), opt(argv, "--sequences", 4)
+    out = {}
+    for s in range(S):
+        scans, _, _, model = syn.make_sequence(sensor, T, seed=100 + s)
+        for k, x in enumerate(scans):
+            out[f"s{s}_f{k}"] = x.numpy().astype(np.float32)
+    out["meta"] = np.array(json.dumps({"sensor": sensor, "frames": T, "sequences": S, "n_scans": model.n_scans, "min_range": model.min_range,
+                                       "ring_from_field": bool(model.ring_from_field), "columns": model.columns}))
+    np.savez_compressed(INPUTS, **out)
+    print(INPUTS, os.path.getsize(INPUTS) >> 20, "MiB")
+
+
+class Hip:
+    """the three runtime calls the harness needs, through ctypes"""
+
+    def __init__(self):
+        self.l = C.CDLL("libamdhip64.so")
+        self.l.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.l.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.l.hipFree.argtypes = [C.c_void_p]
+
+    def malloc(self, n):
+        p = C.c_void_p()
+        rc = self.l.hipMalloc(C.byref(p), n)
+        assert rc == 0 and p.value, f"hipMalloc({n}) -> {rc}"
+        return p.value
+
+    def h2d(self, dst, arr):
+        assert self.l.hipMemcpy(dst, arr.ctypes.data, arr.nbytes, 1) == 0
+
+    def d2d(self, dst, src, n):
+        assert self.l.hipMemcpy(dst, src, n, 3) == 0
+
+    def free(self, p):
+        self.l.hipFree(p)
+
+
+def run(argv):
+    lib_path, out_path = argv[0], argv[1]
+    if lib_path != "product":
+        os.environ["ALOAM_MI355X_LIB"] = os.path.abspath(lib_path)
+    B, steps, mapping = opt(argv, "--batch", 1024), opt(argv, "--steps", 12), "--mapping" in argv
+    binding = importlib.import_module("a-loam_amd.binding")
+    z = np.load(INPUTS)
+    meta = json.loads(str(z["meta"]))
+    T, S = meta["frames"], meta["sequences"]
+    NP = max(z[f"s{s}_f{k}"].shape[0] for s in range(S) for k in range(T))
+    NP = (NP + 255) // 256 * 256
+    hip = Hip()
+    seq_stride = T * NP * 16
+    base = hip.malloc(B * seq_stride)
+    counts = np.zeros((B, T), np.int32)
+    for s in range(min(S, B)):                                   # stored sequence s -> batch slot s, then device-to-device into s + S, s + 2 S, ...
+        for k in range(T):
+            x = np.ascontiguousarray(z[f"s{s}_f{k}"][:, :4], np.float32)
+            hip.h2d(base + s * seq_stride + k * NP * 16, x)
+            counts[s::S, k] = x.shape[0]
+        for b in range(s + S, B, S):
+            hip.d2d(base + b * seq_stride, base + s * seq_stride, seq_stride)
+    gpu = binding.Aloam(n_scans=meta["n_scans"], min_range=meta["min_range"], ring_from_field=meta["ring_from_field"], batch=B, max_points=NP,
+                        max_ring_points=2059 if meta["columns"] <= 2048 else 4107)
+    if mapping:
+        gpu.mapping_enable(0.4, 0.8, pool_points=262144)
+    order, t, d = [], 0, 1                                       # ping-pong replay of the stored frames, like bench.py's frame_order
+    for _ in range(steps):
+        order.append(t)
+        if T > 1:
+            if t + d < 0 or t + d >= T:
+                d = -d
+            t += d
+    watch = sorted({0, min(1, B - 1), B - 1})
+    rec = {}
+    nin = {k: (C.c_int * B)(*[int(v) for v in counts[:, k]]) for k in range(T)}
+    gpu.profile_enable(True)
+    t0 = time.perf_counter()
+    for i, k in enumerate(order):
+        gpu.process_device(base + k * NP * 16, seq_stride, nin[k])
+        if mapping:
+            gpu.mapping_step()
+        if i < 2 * T or i == steps - 1:                          # outputs of the first two passes over the frames and of the last step
+            gpu.synchronize()
+            for b in watch:
+                f = gpu.features(b)
+                for name in ("sharp", "less_sharp", "flat", "less_flat"):
+                    rec[f"step{i}_seq{b}_{name}"] = f[name]
+                rec[f"step{i}_seq{b}_corner_last"] = gpu.cloud(binding.CLOUD_CORNER_LAST, b)
+                rec[f"step{i}_seq{b}_surf_last"] = gpu.cloud(binding.CLOUD_SURF_LAST, b)
+                p = gpu.pose(b)
+                rec[f"step{i}_seq{b}_pose"] = np.concatenate([p["q_w"], p["t_w"], p["q_lc"], p["t_lc"]])
+                st = gpu.odom_stats(b)
+                rec[f"step{i}_seq{b}_stats"] = np.array([v for key in sorted(st) for v in st[key]], np.float64)
+                if mapping:
+                    m = gpu.map_pose(b)
+                    rec[f"step{i}_seq{b}_map_pose"] = np.concatenate([m["q_w"], m["t_w"]])
+                    rec[f"step{i}_seq{b}_map_info"] = np.array(list(gpu.map_info(b).values()), np.int64)
+    gpu.synchronize()
+    wall = time.perf_counter() - t0
+    prof = gpu.profile()
+    rec["profile"] = np.array(json.dumps({"lib": lib_path, "batch": B, "steps": steps, "mapping": mapping, "wall_s_with_readbacks": wall,
+                                          "ms_per_step": {k: v["total_ms"] / steps for k, v in prof.items() if v["launches"]}}))
+    np.savez(out_path, **rec)
+    gpu.close()
+    hip.free(base)
+    print(lib_path, "->", out_path, "kernel ms per step:", round(sum(v["total_ms"] for v in prof.values()) / steps, 3))
+
+
+def compare(argv):
+    a, b = np.load(argv[0]), np.load(argv[1])
+    pa, pb = json.loads(str(a["profile"])), json.loads(str(b["profile"]))
+    keys = sorted(k for k in a.files if k != "profile")
+    assert keys == sorted(k for k in b.files if k != "profile"), "the two runs recorded different outputs"
+    bad = [k for k in keys if a[k].shape != b[k].shape or not np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8))]
+    print(f"{len(keys) - len(bad)} of {len(keys)} recorded arrays bit-identical" + (f"; DIFFERENT: {bad[:12]}" if bad else ""))
+    print(f"{'kernel':28s} {pa['lib'][-28:]:>28s} {pb['lib'][-28:]:>28s}   (ms per {pa['batch']}-sequence step)")
+    for k in pa["ms_per_step"]:
+        x, y = pa["ms_per_step"][k], pb["ms_per_step"].get(k, float("nan"))
+        print(f"{k:28s} {x:28.4f} {y:28.4f}   {100 * (y - x) / x if x else 0:+.1f} %")
+    sa, sb = sum(pa["ms_per_step"].values()), sum(pb["ms_per_step"].values())
+    print(f"{'sum':28s} {sa:28.4f} {sb:28.4f}   {100 * (sb - sa) / sa:+.1f} %")
+    return 1 if bad else 0
+
+
+def ab(argv):
+    libs, rest = argv[:2], argv[2:]
+    outs = []
+    for i, l in enumerate(libs):
+        out = os.path.join(ROOT, "gpurun_out", f"ab_{i}.npz")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "run", l, out, *rest])
+        if r.returncode:
+            raise SystemExit(f"run with {l} failed")
+        outs.append(out)
+    return compare(outs)
+
+
+if __name__ == "__main__":
+    cmd, args = sys.argv[1], sys.argv[2:]
+    sys.exit({"make-inputs": make_inputs, "run": run, "compare": compare, "ab": ab}[cmd](args) or 0)
