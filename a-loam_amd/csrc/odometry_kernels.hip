@@ -779,6 +779,324 @@ __global__ __launch_bounds__(64) void k_associate(OdomArgs a) {
 }
 
 // -------------------------------------------------------------------------------------------------------
+// TWO queries per wave (round 4).  The wave-per-query kernel above spends two thirds of its ~600 VALU instructions per query on
+// work that does not depend on the lane: bucket hashes, scans, the owner spread of every row of candidates, five wave minima, the
+// ring-grid look-ups.  Here a wave serves two consecutive queries of one sequence, one per HALF of 32 lanes: every one of those
+// instructions now does its work for two queries, the per-candidate work (one lane = one candidate) is unchanged.  Scans and minima
+// stop at the half border (the row_bcast:31 step of the DPP ladders is left out); what the one-query form keeps in scalar registers
+// (closest point, its ring, the class bounds, "done") is half-uniform data in vector registers, broadcast from the last lane of the
+// half with one ds_bpermute; early exits become per-half masks and the wave leaves a phase when neither half needs it.
+// Trackers hold the packed key only: the winners' coordinates are read from the ring-ordered cloud by index at the very end (grid
+// entries are copies of those points), and the candidates a half keeps from its fine block are (distance, index | ring) pairs, so six
+// rows of 32 cost the registers three rows of 64 cost before.  Sequences whose clouds are flagged (not ring-sorted, coordinates
+// or keys out of range) are left to k_associate_flagged, which runs the literal one-query code above.
+template <bool MAX>
+__device__ __forceinline__ int half_scan_i32(int v) {                         // inclusive scan inside each half of 32 lanes
+  constexpr int identity = MAX ? (int)0x80000000 : 0;
+  auto op = [](int a, int b) { return MAX ? (a > b ? a : b) : a + b; };
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xF, 0xF, false));   // row_shr:1
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xF, 0xF, false));   // row_shr:2
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xF, 0xF, false));   // row_shr:4
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xF, 0xF, false));   // row_shr:8
+  v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  return v;
+}
+__device__ __forceinline__ unsigned half_min_ladder(unsigned v) {             // lanes 31 and 63 end up with the minimum of their half
+  auto op = [](unsigned a, unsigned b) { return a < b ? a : b; };
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x111, 0xF, 0xF, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x112, 0xF, 0xF, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x114, 0xF, 0xF, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x118, 0xF, 0xF, false));
+  v = op(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, 0x142, 0xA, 0xF, false));
+  return v;
+}
+// value of the last lane of the own half, for every lane (`last4` = (lane | 31) * 4)
+__device__ __forceinline__ int half_last(int v, int last4) { return __builtin_amdgcn_ds_bpermute(last4, v); }
+// minimum of packed (distance bits << 32 | tie-break) keys per half, in every lane of the half
+__device__ __forceinline__ unsigned long long half_min_packed(unsigned long long v, int last4) {
+  const unsigned hi = (unsigned)(v >> 32), lo = (unsigned)v;
+  const unsigned mh = (unsigned)half_last((int)half_min_ladder(hi), last4);
+  const unsigned ml = (unsigned)half_last((int)half_min_ladder(hi == mh ? lo : 0xffffffffu), last4);
+  return ((unsigned long long)mh << 32) | ml;
+}
+
+template <int kRows> struct KeptPair { float d[kRows]; unsigned w[kRows]; unsigned act; bool ok; };
+
+// wave_sweep for two independent bucket lists, one per half: lane L of a half owns bucket [s0, s0 + cnt) of ITS half's list; row u of a
+// round holds positions base + 32 u .. + 31 of both lists side by side (LDS row u: half 0 in words 0..31, half 1 in 32..63).  The rounds are
+// shared: a half whose list is shorter idles.  f(p, active, u, first_round).
+template <int kRows, class F>
+__device__ __forceinline__ void pair_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int last4, int* row, F&& f, bool* single_round = nullptr) {
+  const int incl = half_scan_i32<false>(cnt);
+  const int total = half_last(incl, last4);
+  const int t0 = __builtin_amdgcn_readlane(incl, 31), t1 = __builtin_amdgcn_readlane(incl, 63);
+  const int tmax = t0 > t1 ? t0 : t1;
+  const int excl = incl - cnt, l = lane & 31, hb = lane & 32;
+  if (single_round) *single_round = total <= kRows * 32;
+  int carry = 0;                                                           // owner + 1 of the position before `base` (per half)
+  for (int base = 0; base < tmax; base += kRows * 32) {
+    const int slot = excl - base;
+    const int rows = tmax - base > (kRows - 1) * 32 ? kRows : (tmax - base + 31) >> 5;       // uniform: rows in use this round
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) if (u < rows) row[u * 64 + lane] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (cnt > 0 && slot >= 0 && slot < rows * 32) row[((slot >> 5) << 6) + hb + (slot & 31)] = lane + 1;
+    __builtin_amdgcn_wave_barrier();
+    int own[kRows], top[kRows];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) own[u] = u < rows ? row[u * 64 + lane] : 0;
+    __builtin_amdgcn_wave_barrier();
+    // owners: max-scan inside the row and half; what the rows in front carry over is a plain maximum on top of the scanned value, so
+    // the six scans and the broadcasts of their row maxima are independent of each other
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) if (u < rows) { own[u] = half_scan_i32<true>(own[u]); top[u] = half_last(own[u], last4); }
+    float4 p[kRows];
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) {
+      p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < rows) {
+        own[u] = own[u] > carry ? own[u] : carry;
+        carry = top[u] > carry ? top[u] : carry;
+        const int i = base + u * 32 + l;
+        const int src4 = (own[u] - 1) << 2;
+        const int os = __builtin_amdgcn_ds_bpermute(src4, s0), oe = __builtin_amdgcn_ds_bpermute(src4, excl);
+        const int at = i < total ? os + (i - oe) : 0;
+        p[u] = sorted[at];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kRows; ++u) if (u < rows) f(p[u], base + u * 32 + l < total, u, base == 0);
+  }
+}
+
+#ifndef ALOAM_PAIR_ROWS_PLANE
+#define ALOAM_PAIR_ROWS_PLANE 6      // rows of 32 candidates per half in flight / kept (A/B builds)
+#endif
+#ifndef ALOAM_PAIR_ROWS_CORNER
+#define ALOAM_PAIR_ROWS_CORNER 4
+#endif
+#ifndef ALOAM_PAIR_ROWS_WIDE
+#define ALOAM_PAIR_ROWS_WIDE 8
+#endif
+template <bool PLANE, bool WIDE> struct PairRows { static constexpr int value = WIDE ? (PLANE ? ALOAM_PAIR_ROWS_WIDE : ALOAM_PAIR_ROWS_PLANE) : (PLANE ? ALOAM_PAIR_ROWS_PLANE : ALOAM_PAIR_ROWS_CORNER); };
+
+template <bool PLANE, int kRows>
+__device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0, int nq, const SeqMeta& m, const GridView& g, int lane, int* row) {
+  const int l = lane & 31, last4 = (lane | 31) << 2;
+  const int qi = qi0 + (lane >> 5);
+  const bool qact = qi < nq;
+  const int qcap = PLANE ? a.R * 24 : a.R * 12;
+  const long long qo = (long long)b * qcap + (qact ? qi : qi0);
+  const float4 raw = (PLANE ? a.flat : a.sharp)[qo];
+  const float4 sel = (PLANE ? a.sel_flat : a.sel_sharp)[qo];                 // k_transform_queries
+  const float frac = raw.w - (float)(int)raw.w;                              // relTime of the point (:116)
+  const float4* T = PLANE ? a.surf_last + (long long)b * a.cap : a.corner_last + (long long)b * a.R * 120;
+  const unsigned hm = (unsigned)(g.H - 1);
+  const float cell = cell3_of(PLANE ? 1 : 0);
+
+  // ---- exact 1-NN: the 3x3x3 block of fine cells, its candidates kept as (distance, index | ring)
+  unsigned long long t1 = ~0ull;
+  KeptPair<kRows> kept;
+  kept.act = 0u;
+#pragma unroll
+  for (int u = 0; u < kRows; ++u) { kept.d[u] = 0.f; kept.w[u] = 0u; }
+  auto dist = [&](const float4& p) {
+    const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
+    return (ddx * ddx + ddy * ddy) + ddz * ddz;                              // FLANN's L2_Simple sum = the walk's f32 expression (:322-327)
+  };
+  auto key1 = [](float d, unsigned wb) { return ((unsigned long long)__float_as_uint(d) << 32) | ((wb & kIdxMask) << 12) | (wb >> 20); };
+  {
+    const float inv = 1.0f / cell;
+    const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv), cz = (int)floorf(sel.z * inv);
+    int s0 = 0, cnt = 0;
+    if (l < 27 && qact) {
+      const unsigned h = hash3(cx + l % 3 - 1, cy + (l % 9) / 3 - 1, cz + l / 9 - 1) & hm;
+      s0 = g.start3[h];
+      cnt = g.start3[h + 1] - s0;
+    }
+    pair_sweep<kRows>(g.sorted3, s0, cnt, lane, last4, row, [&](const float4& p, bool act, int u, bool first) {
+      const float d = dist(p);
+      const unsigned wb = __float_as_uint(p.w);
+      if (first) { kept.d[u] = d; kept.w[u] = wb; kept.act |= act ? 1u << u : 0u; }
+      const unsigned long long v = key1(d, wb);
+      if (act && v < t1) t1 = v;
+    }, &kept.ok);
+  }
+  unsigned long long nn = half_min_packed(t1, last4);
+  {
+    const float bound = (1.0f - 0.01f) * cell;                               // every unvisited point is farther than `bound`
+    bool need = qact && !(nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= bound * bound);
+    if (__ballot(need)) {
+      // expanding cubic shells of coarse cells (at most three steps reach DISTANCE_SQ_THRESHOLD), for the halves that need them
+      const float cellc = cell * kCell3CoarseFactor, invc = 1.0f / cellc;
+      const int ux = (int)floorf(sel.x * invc), uy = (int)floorf(sel.y * invc), uz = (int)floorf(sel.z * invc);
+      for (int r = 1;; ++r) {
+        const int ncell = r == 1 ? 27 : 24 * r * r + 2;
+        const float limit = nn != ~0ull ? fminf(__uint_as_float((unsigned)(nn >> 32)), 25.0f) : 25.0f;
+        for (int cb = 0; cb < ncell; cb += 32) {
+          const int c = cb + l;
+          int s0 = 0, cnt = 0;
+          if (need && c < ncell) {
+            int dx, dy, dz;
+            if (r == 1) { dz = c / 9 - 1; dy = (c % 9) / 3 - 1; dx = c % 3 - 1; }
+            else shell3d(r, c, &dx, &dy, &dz);
+            const float gx = cell_gap(sel.x, ux + dx, cellc), gy = cell_gap(sel.y, uy + dy, cellc), gz = cell_gap(sel.z, uz + dz, cellc);
+            if (((gx * gx + gy * gy) + gz * gz) * 0.999f <= limit) {
+              const unsigned h = hash3(ux + dx, uy + dy, uz + dz) & hm;
+              s0 = g.start3c[h];
+              cnt = g.start3c[h + 1] - s0;
+            }
+          }
+          pair_sweep<kRows>(g.sorted3c, s0, cnt, lane, last4, row, [&](const float4& p, bool act, int, bool) {
+            const unsigned long long v = key1(dist(p), __float_as_uint(p.w));
+            if (act && v < t1) t1 = v;
+          });
+        }
+        nn = half_min_packed(t1, last4);
+        const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
+        if (nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= b2) need = false;
+        if (b2 >= 25.0f || !__ballot(need)) break;                          // nothing within DISTANCE_SQ_THRESHOLD is left
+      }
+    }
+  }
+
+  // ---- second / third neighbour (:304-361 / :392-455), window form (ring-sorted clouds only: the caller checked)
+  const float nnd = __uint_as_float((unsigned)(nn >> 32));
+  const bool has1 = qact && nn != ~0ull && (double)nnd < 25.0;               // DISTANCE_SQ_THRESHOLD (:65,305,393)
+  const int closest = (int)((unsigned)nn >> 12);
+  const int cid = (int)((unsigned)nn & 0xfffu) - 1;                          // closestPointScanID (:308,398)
+  unsigned long long t2 = ~0ull, t3 = ~0ull, best2 = ~0ull, best3 = ~0ull;
+  auto consider = [&](float d, unsigned wb, bool act) {
+    const int j = (int)(wb & kIdxMask), key = (int)(wb >> 20) - 1;
+    const bool up = j > closest;
+    bool c2, c3;
+    if (PLANE) { c2 = up ? key <= cid : key >= cid; c3 = !c2; }           // :416-426, :444-454
+    else { c2 = up ? key > cid : key < cid; c3 = false; }                 // :315-316, :341-342 (`continue` on the same side)
+    const bool ok = act && j != closest && (unsigned)(key - cid + 2) <= 4u && (double)d < 25.0;
+    const unsigned seq = up ? (unsigned)(j - closest) : 0x40000000u + (unsigned)(closest - j);
+    const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | seq;
+    if (ok && c2 && v < t2) t2 = v;
+    if (PLANE && ok && c3 && v < t3) t3 = v;
+  };
+  bool want2 = has1, want3 = PLANE && has1;
+  float lim2 = 25.0f, lim3 = 25.0f;
+  if (__ballot(has1)) {
+    {
+      // the candidates of the fine block are still in registers: neighbours found there within (almost) one cell are final
+      const bool use = has1 && kept.ok;
+#pragma unroll
+      for (int u = 0; u < kRows; ++u) consider(kept.d[u], kept.w[u], use && ((kept.act >> u) & 1u));
+      best2 = half_min_packed(t2, last4);
+      if (PLANE) best3 = half_min_packed(t3, last4);
+      const float bound = (1.0f - 0.01f) * cell, b2 = bound * bound;
+      if (best2 != ~0ull) lim2 = __uint_as_float((unsigned)(best2 >> 32));
+      if (PLANE && best3 != ~0ull) lim3 = __uint_as_float((unsigned)(best3 >> 32));
+      if (use && best2 != ~0ull && lim2 <= b2) want2 = false;
+      if (use && PLANE && best3 != ~0ull && lim3 <= b2) want3 = false;
+    }
+    // ring grid: the 3x3 block of cells around the query, then the 16 cells around it (two cells = 5.25 m cover
+    // DISTANCE_SQ_THRESHOLD); per cell the ring keys cid +-1, +-2 (the other rings) and, planar class, cid itself.  Cells that cannot hold
+    // anything closer than the class's best so far are skipped.
+    for (int level = 0; level < 2 && __ballot(want2 || want3); ++level) {
+      const float rc = kCell2, inv = 1.0f / rc;
+      const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv);
+      const int ncell = level == 0 ? 9 : 16;
+      // look-ups of a half: first the other rings (4 keys per cell), then the own ring (planar class only)
+      const bool wo = PLANE ? want3 : want2, ws = PLANE && want2;          // other rings wanted / own ring wanted
+      const int n_other = wo ? 4 * ncell : 0, n_look = n_other + (ws ? ncell : 0);
+      const int nl0 = __builtin_amdgcn_readlane(n_look, 0), nl1 = __builtin_amdgcn_readlane(n_look, 32), nlmax = nl0 > nl1 ? nl0 : nl1;
+      for (int lb = 0; lb < nlmax; lb += 32) {
+        const int k = lb + l;
+        int s0 = 0, cnt = 0;
+        if (k < n_look) {
+          const bool other = k < n_other;
+          const int cc = other ? k >> 2 : k - n_other, ko = k & 3;
+          const int key = other ? cid + ((ko & 1) ? 1 : -1) * ((ko >> 1) + 1) : cid;
+          int ddx, ddy;
+          if (level == 0) { ddx = cc % 3 - 1; ddy = cc / 3 - 1; } else ring2d(2, cc, &ddx, &ddy);
+          const float gx = cell_gap(sel.x, cx + ddx, rc), gy = cell_gap(sel.y, cy + ddy, rc);
+          const bool second = PLANE ? !other : true;
+          if (key >= 0 && (gx * gx + gy * gy) * 0.999f <= (second ? lim2 : lim3)) {
+            const unsigned h = hash3(cx + ddx, cy + ddy, key) & hm;
+            s0 = g.start2[h];
+            cnt = g.start2[h + 1] - s0;
+          }
+        }
+        pair_sweep<kRows>(g.sorted2, s0, cnt, lane, last4, row, [&](const float4& p, bool act, int, bool) { consider(dist(p), __float_as_uint(p.w), act); });
+      }
+      best2 = half_min_packed(t2, last4);
+      if (PLANE) best3 = half_min_packed(t3, last4);
+      const float bound = ((float)(level + 1) - 0.01f) * rc, b2 = bound * bound;
+      if (b2 >= 25.0f) break;
+      if (best2 != ~0ull) lim2 = __uint_as_float((unsigned)(best2 >> 32));
+      if (PLANE && best3 != ~0ull) lim3 = __uint_as_float((unsigned)(best3 >> 32));
+      if (best2 != ~0ull && lim2 <= b2) want2 = false;
+      if (PLANE && best3 != ~0ull && lim3 <= b2) want3 = false;
+    }
+  }
+  const bool valid = has1 && best2 != ~0ull && (!PLANE || best3 != ~0ull);   // :363 / :457
+
+  // ---- the record: lane 0 of the half stores the raw, untransformed point (:365-367 / :460-462), lanes 1.. the neighbours (read from the
+  // ring-ordered cloud by index: the grid entries are copies of exactly those points), the next lane the flag and the relTime
+  if (qact) {
+    constexpr int kPts = PLANE ? 4 : 3;
+    float* e = PLANE ? reinterpret_cast<float*>(a.planes + (long long)b * a.R * 24 + qi) : reinterpret_cast<float*>(a.edges + (long long)b * a.R * 12 + qi);
+    if (l < kPts) {
+      float x = raw.x, y = raw.y, z = raw.z;
+      if (l > 0) {
+        x = y = z = 0.f;
+        if (valid) {
+          const unsigned long long bw = l == 2 ? best2 : best3;
+          const unsigned seq = (unsigned)bw;
+          const int j = l == 1 ? closest : (seq < 0x40000000u ? closest + (int)seq : closest - (int)(seq - 0x40000000u));
+          const float4 p = T[j];
+          x = p.x; y = p.y; z = p.z;
+        }
+      }
+      e[3 * l] = x; e[3 * l + 1] = y; e[3 * l + 2] = z;
+    } else if (l == kPts) {
+      int* ei = reinterpret_cast<int*>(e) + 3 * kPts;
+      ei[0] = valid ? 1 : 0; ei[1] = __float_as_int(frac); ei[2] = 0;
+      if (PLANE) ei[3] = 0;
+    }
+  }
+}
+
+template <bool PLANE, bool WIDE>
+__global__ __launch_bounds__(64) void k_associate_pair(OdomArgs a) {
+  constexpr int kRows = PairRows<PLANE, WIDE>::value;
+  __shared__ int row[kRows * 64];
+  // XCD-aware work mapping as in k_associate: XCD x works through sequences x, x + 8, ...
+  const int lane = threadIdx.x, L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int pairs = PLANE ? a.R * 12 : a.R * 6;
+  const int b = (slot / pairs) * 8 + xcd, qi0 = (slot % pairs) * 2;
+  if (b >= a.B) return;
+  const SeqMeta m = a.meta[b];
+  const int nq = PLANE ? m.n_flat : m.n_sharp;
+  if (qi0 >= nq) return;
+  const GridView g = grid_view(a, b, PLANE ? 1 : 0);
+  const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
+  if (g.flags[0] != 0 || g.flags[1] != 0 || nt <= 0) return;                 // k_associate_flagged owns this sequence
+  associate_pair<PLANE, kRows>(a, b, qi0, nq, m, g, lane, row);
+}
+
+// Sequences the pair kernel leaves alone: clouds that are not ring-sorted or hold keys / coordinates outside the range the grids are
+// exact for (possible through aloam_set_last), and empty clouds.  One workgroup of four waves per sequence walks through its queries with
+// the literal one-query code; for every other sequence the workgroup returns at once.
+template <bool PLANE, bool DISTORT, bool WIDE>
+__global__ __launch_bounds__(256) void k_associate_flagged(OdomArgs a) {
+  constexpr int kSweep = SweepRows<PLANE, WIDE>::value;
+  __shared__ int rows[4][kSweep * 64];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const SeqMeta m = a.meta[b];
+  const GridView g = grid_view(a, b, PLANE ? 1 : 0);
+  const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
+  if (!(g.flags[0] != 0 || g.flags[1] != 0 || nt <= 0)) return;
+  const int nq = PLANE ? m.n_flat : m.n_sharp;
+  for (int qi = wave; qi < nq; qi += 4) associate_one<PLANE, DISTORT, WIDE>(a, b, qi, m, g, lane, rows[wave]);
+}
+
+// -------------------------------------------------------------------------------------------------------
 #ifndef ALOAM_SOLVE_WAVES
 #define ALOAM_SOLVE_WAVES 2      // waves per sequence in k_solve; measured at batch 512: 1: 0.62 ms, 2: 0.44, 4: 0.53, 8: 0.87 (two launches)
 #endif
@@ -934,13 +1252,34 @@ void launch_transform_queries(const OdomArgs& a, hipStream_t s) {
   if (a.distortion) hipLaunchKernelGGL(k_transform_queries<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_transform_queries<false>, grid, dim3(256), 0, s, a);
 }
+#ifndef ALOAM_ASSOC_PAIR
+#define ALOAM_ASSOC_PAIR 1      // A/B builds: 0 = the one-query-per-wave kernel of rounds 1-3, 1 = two queries per wave for the corner class
+#endif                          // (measured, batch 1024, two launches: corner 1.048 -> 0.875 ms, planar 2.85 -> 3.03 ms), 2 = for both classes
 void launch_associate(const OdomArgs& a, bool plane, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
   const int qcap = plane ? a.R * 24 : a.R * 12;   // the kernel decodes (sequence, query) from blockIdx.x with exactly this slot count
-  const dim3 grid((unsigned)(qcap * by)), block(64);
   // sensors with more than 64 rings: the ring grid's +-2-ring window and the fine blocks hold about twice the candidates, so the
-  // waves keep more rows of 64 candidates in flight per sweep round (kSweep by class AND ring count)
+  // waves keep more rows of candidates in flight per sweep round (rows by class AND ring count)
   const bool wide = a.R > 64;
+  if (ALOAM_ASSOC_PAIR == 2 || (ALOAM_ASSOC_PAIR == 1 && !plane)) {
+    const dim3 grid((unsigned)(qcap / 2 * by)), block(64), gridf((unsigned)a.B), blockf(256);
+    if (wide) {
+      if (plane) hipLaunchKernelGGL((k_associate_pair<true, true>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((k_associate_pair<false, true>), grid, block, 0, s, a);
+    } else {
+      if (plane) hipLaunchKernelGGL((k_associate_pair<true, false>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((k_associate_pair<false, false>), grid, block, 0, s, a);
+    }
+    if (wide) {
+      if (plane) hipLaunchKernelGGL((k_associate_flagged<true, false, true>), gridf, blockf, 0, s, a);
+      else hipLaunchKernelGGL((k_associate_flagged<false, false, true>), gridf, blockf, 0, s, a);
+    } else {
+      if (plane) hipLaunchKernelGGL((k_associate_flagged<true, false, false>), gridf, blockf, 0, s, a);
+      else hipLaunchKernelGGL((k_associate_flagged<false, false, false>), gridf, blockf, 0, s, a);
+    }
+    return;
+  }
+  const dim3 grid((unsigned)(qcap * by)), block(64);
   if (a.distortion) {
     if (plane) hipLaunchKernelGGL((k_associate<true, true>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_associate<false, true>), grid, block, 0, s, a);
