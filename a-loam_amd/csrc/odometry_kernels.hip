@@ -820,52 +820,92 @@ __device__ __forceinline__ unsigned long long half_min_packed(unsigned long long
   return ((unsigned long long)mh << 32) | ml;
 }
 
-template <int kRows> struct KeptPair { float d[kRows]; unsigned w[kRows]; unsigned act; bool ok; };
+// ---- sweeps whose VALU cost per row of candidates is a few instructions --------------------------------------------------------
+// The kernels are bound by the number of vector instructions a wave issues (SQ counters: 97 % of the VALU issue cycles busy), so the
+// owner of a list position is found with LDS and scalar work instead of a max-scan on the DPP network:
+//  * every non-empty bucket sets ONE bit, at the last position it owns, in a bit mask per row (ds_or); the number of buckets in front
+//    of position i is then v_mbcnt of the row's mask plus a running popcount — its rank among the non-empty buckets;
+//  * the non-empty buckets leave (first entry - first position) in a table at their rank (ballot + v_mbcnt), so a position needs one
+//    LDS read and one addition to get the index of its grid entry;
+//  * lanes beyond the end of the list do not idle behind a flag: their index is clamped to the cloud and they look at whatever grid
+//    entry it names.  Every entry is a point of the cloud with its true index and ring, and every search here is a minimum over a SUPERSET
+//    of the candidates it needs (the reference's walks look at the whole ring window), so extra real points cannot change a result.
+// HALVES: two independent lists, one per half of 32 lanes (rows of 32 positions, side by side); otherwise one list, rows of 64.
+// LDS of a wave: mark slots of four dwords {mask of lanes 0-31, mask of lanes 32-63, both, -} — HALVES: slot (row, half), the half's 32-bit
+// mask in the dword that v_mbcnt reads for its lanes; else slot (row) — then table[72].
+template <int kRows> struct KeptPair { unsigned long long k[kRows]; bool ok; };                 // packed 1-NN keys (distance, index << 12 | ring + 1)
+template <int kRows> constexpr int sweep2_lds_ints() { return kRows * 8 + 72; }
 
-// wave_sweep for two independent bucket lists, one per half: lane L of a half owns bucket [s0, s0 + cnt) of ITS half's list; row u of a
-// round holds positions base + 32 u .. + 31 of both lists side by side (LDS row u: half 0 in words 0..31, half 1 in 32..63).  The rounds are
-// shared: a half whose list is shorter idles.  f(p, active, u, first_round).
-template <int kRows, class F>
-__device__ __forceinline__ void pair_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int last4, int* row, F&& f, bool* single_round = nullptr) {
-  const int incl = half_scan_i32<false>(cnt);
-  const int total = half_last(incl, last4);
-  const int t0 = __builtin_amdgcn_readlane(incl, 31), t1 = __builtin_amdgcn_readlane(incl, 63);
-  const int tmax = t0 > t1 ? t0 : t1;
-  const int excl = incl - cnt, l = lane & 31, hb = lane & 32;
-  if (single_round) *single_round = total <= kRows * 32;
-  int carry = 0;                                                           // owner + 1 of the position before `base` (per half)
-  for (int base = 0; base < tmax; base += kRows * 32) {
-    const int slot = excl - base;
-    const int rows = tmax - base > (kRows - 1) * 32 ? kRows : (tmax - base + 31) >> 5;       // uniform: rows in use this round
-#pragma unroll
-    for (int u = 0; u < kRows; ++u) if (u < rows) row[u * 64 + lane] = 0;
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dist_to(const float4& p, float2v sxy, float sz) {
+  const float2v pxy = {p.x, p.y};
+  const float2v dxy = pxy - sxy, qxy = dxy * dxy;                             // packed f32: the same two subtractions and products
+  const float ddz = p.z - sz;
+  return (qxy.x + qxy.y) + ddz * ddz;                                         // FLANN's L2_Simple sum = the walk's f32 expression (:322-327)
+}
+
+template <bool HALVES, int kRows, class F>
+__device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsigned last_index, int s0, int cnt, int lane, int last4, int* lds, F&& f, bool* single_round = nullptr) {
+  constexpr int W = HALVES ? 32 : 64, LOGW = HALVES ? 5 : 6, kSlots = HALVES ? 2 * kRows : kRows;
+  unsigned* marks = reinterpret_cast<unsigned*>(lds);
+  int* table = lds + kRows * 8;
+  const int h = HALVES ? lane >> 5 : 0, l = lane & (W - 1);
+  const int incl = HALVES ? half_scan_i32<false>(cnt) : wave_scan_i32<false>(cnt);
+  int total, tmax;
+  if (HALVES) {
+    total = half_last(incl, last4);
+    const int t0 = __builtin_amdgcn_readlane(incl, 31), t1 = __builtin_amdgcn_readlane(incl, 63);
+    tmax = t0 > t1 ? t0 : t1;
+  } else total = tmax = __builtin_amdgcn_readlane(incl, 63);
+  if (single_round) *single_round = total <= kRows * W;
+  if (tmax <= 0) return;
+  const bool nonempty = cnt > 0;
+  const unsigned long long ne = __ballot(nonempty);
+  const int rank_own = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ne >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ne, 0u));
+  if (nonempty) table[rank_own] = s0 - (incl - cnt);                          // entry index = position + this
+  const int rank0 = HALVES && h ? __builtin_popcount((unsigned)ne) : 0;       // rank of the half's first non-empty bucket
+  const int pl = incl - 1;                                                    // last position the bucket owns
+  const char* const bytes = reinterpret_cast<const char*>(sorted);
+  for (int base = 0; base < tmax; base += kRows * W) {
+    const int rows = tmax - base > (kRows - 1) * W ? kRows : (tmax - base + W - 1) >> LOGW;   // uniform: rows in use this round
+    if (lane < kSlots * 4) marks[lane] = 0u;
     __builtin_amdgcn_wave_barrier();
-    if (cnt > 0 && slot >= 0 && slot < rows * 32) row[((slot >> 5) << 6) + hb + (slot & 31)] = lane + 1;
+    const int pr = pl - base;
+    if (nonempty && pr >= 0 && pr < kRows * W) {
+      const int r = pr >> LOGW, bit = pr & (W - 1);
+      unsigned* slot = marks + (HALVES ? (r * 2 + h) * 4 : r * 4);
+      atomicOr(slot + (HALVES ? h : bit >> 5), 1u << (bit & 31));
+      if (HALVES) atomicOr(slot + 2, 1u << (bit & 31));
+    }
     __builtin_amdgcn_wave_barrier();
-    int own[kRows], top[kRows];
-#pragma unroll
-    for (int u = 0; u < kRows; ++u) own[u] = u < rows ? row[u * 64 + lane] : 0;
-    __builtin_amdgcn_wave_barrier();
-    // owners: max-scan inside the row and half; what the rows in front carry over is a plain maximum on top of the scanned value, so
-    // the six scans and the broadcasts of their row maxima are independent of each other
-#pragma unroll
-    for (int u = 0; u < kRows; ++u) if (u < rows) { own[u] = half_scan_i32<true>(own[u]); top[u] = half_last(own[u], last4); }
+    int carry = rank0;                                                        // rank of the owner of the first position of the row
+    if (base > 0) {                                                           // buckets that ended in earlier rounds
+      const unsigned long long before = __ballot(nonempty && pl < base);
+      carry += HALVES ? (h ? __builtin_popcount((unsigned)(before >> 32)) : __builtin_popcount((unsigned)before)) : __builtin_popcountll(before);
+    }
     float4 p[kRows];
 #pragma unroll
     for (int u = 0; u < kRows; ++u) {
       p[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (u < rows) {
-        own[u] = own[u] > carry ? own[u] : carry;
-        carry = top[u] > carry ? top[u] : carry;
-        const int i = base + u * 32 + l;
-        const int src4 = (own[u] - 1) << 2;
-        const int os = __builtin_amdgcn_ds_bpermute(src4, s0), oe = __builtin_amdgcn_ds_bpermute(src4, excl);
-        const int at = i < total ? os + (i - oe) : 0;
-        p[u] = sorted[at];
+        const unsigned* slot = marks + (HALVES ? (u * 2 + h) * 4 : u * 4);
+        int rank;
+        if (HALVES) {
+          const uint3 m = *reinterpret_cast<const uint3*>(slot);
+          rank = (int)__builtin_amdgcn_mbcnt_hi(m.y, __builtin_amdgcn_mbcnt_lo(m.x, (unsigned)carry));
+          carry = __builtin_popcount(m.z) + carry;
+        } else {
+          const uint2 m = *reinterpret_cast<const uint2*>(slot);
+          rank = (int)__builtin_amdgcn_mbcnt_hi(m.y, __builtin_amdgcn_mbcnt_lo(m.x, (unsigned)carry));
+          carry = __builtin_popcount(m.x) + carry;
+          carry = __builtin_popcount(m.y) + carry;
+        }
+        const unsigned at = (unsigned)(table[rank] + (base + u * W + l));
+        p[u] = *reinterpret_cast<const float4*>(bytes + ((at < last_index ? at : last_index) << 4));
       }
     }
 #pragma unroll
-    for (int u = 0; u < kRows; ++u) if (u < rows) f(p[u], base + u * 32 + l < total, u, base == 0);
+    for (int u = 0; u < kRows; ++u) if (u < rows) f(p[u], u, base == 0);
   }
 }
 
@@ -880,10 +920,127 @@ __device__ __forceinline__ void pair_sweep(const float4* __restrict__ sorted, in
 #endif
 template <bool PLANE, bool WIDE> struct PairRows { static constexpr int value = WIDE ? (PLANE ? ALOAM_PAIR_ROWS_WIDE : ALOAM_PAIR_ROWS_PLANE) : (PLANE ? ALOAM_PAIR_ROWS_PLANE : ALOAM_PAIR_ROWS_CORNER); };
 
+__device__ __forceinline__ unsigned long long nn_key(float d, unsigned wb) { return ((unsigned long long)__float_as_uint(d) << 32) | ((wb & kIdxMask) << 12) | (wb >> 20); }
+__device__ __forceinline__ void take_min(unsigned long long& t, unsigned long long v) { t = v < t ? v : t; }
+
+// Second / third neighbour of the window form (ring-sorted clouds: j > closest implies key >= cid, so "key <= cid on the way up, key >= cid on
+// the way down" (:416-426, :444-454) is key == cid, and the corner class's "key > cid up, key < cid down" (:315-316, :341-342) is key != cid).
+// Visit order: upward from closest + 1, then downward from closest - 1; first strictly smaller distance wins = lexicographic (distance, order).
+template <bool PLANE>
+__device__ __forceinline__ void consider2(float d, int j, int key, int closest, int cid, unsigned long long& t2, unsigned long long& t3) {
+  const int t = j - closest, nt = closest - j;
+  const unsigned seq = (unsigned)(t > nt ? t : nt) | ((unsigned)t & 0x80000000u);   // up: j - closest; down: 2^31 + closest - j
+  const bool ok = j != closest && (unsigned)(key - cid + 2) <= 4u && d < 25.0f;     // (double)d < 25.0 (:305,393) is the same test: 25 is an f32 number
+  const bool own = key == cid;
+  const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | seq;
+  if (PLANE) {
+    if (ok && own) take_min(t2, v);
+    if (ok && !own) take_min(t3, v);
+  } else if (ok && !own) take_min(t2, v);
+}
+__device__ __forceinline__ int index_of(unsigned long long best, int closest) {
+  const unsigned seq = (unsigned)best;
+  return (seq & 0x80000000u) ? closest - (int)(seq & 0x7fffffffu) : closest + (int)seq;
+}
+
+// ---- the tails, one query at a time on all 64 lanes (state in scalar registers) ----
+// expanding cubic shells of coarse cells around a query whose neighbour is not inside its fine block (at most three steps reach
+// DISTANCE_SQ_THRESHOLD); returns the improved packed 1-NN key
+template <int kRows>
+__device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, unsigned last_index, float cellc, float sx, float sy, float sz, unsigned long long nn, int lane, int* lds) {
+  const float invc = 1.0f / cellc;
+  const float2v sxy = {sx, sy};
+  const int ux = (int)floorf(sx * invc), uy = (int)floorf(sy * invc), uz = (int)floorf(sz * invc);
+  const unsigned hm = (unsigned)(g.H - 1);
+  unsigned long long t1 = nn;
+  for (int r = 1;; ++r) {
+    const int ncell = r == 1 ? 27 : 24 * r * r + 2;
+    const float limit = fminf(__uint_as_float((unsigned)(nn >> 32)), 25.0f);
+    for (int cb = 0; cb < ncell; cb += 64) {
+      const int c = cb + lane;
+      int s0 = 0, cnt = 0;
+      if (c < ncell) {
+        int dx, dy, dz;
+        if (r == 1) { dz = c / 9 - 1; dy = (c % 9) / 3 - 1; dx = c % 3 - 1; }
+        else shell3d(r, c, &dx, &dy, &dz);
+        // a cell farther away than the best candidate so far (or than DISTANCE_SQ_THRESHOLD) cannot change the answer
+        const float gx = cell_gap(sx, ux + dx, cellc), gy = cell_gap(sy, uy + dy, cellc), gz = cell_gap(sz, uz + dz, cellc);
+        if (((gx * gx + gy * gy) + gz * gz) * 0.999f <= limit) {
+          const unsigned hh = hash3(ux + dx, uy + dy, uz + dz) & hm;
+          s0 = g.start3c[hh];
+          cnt = g.start3c[hh + 1] - s0;
+        }
+      }
+      sweep2<false, kRows>(g.sorted3c, last_index, s0, cnt, lane, 0, lds, [&](const float4& p, int, bool) { take_min(t1, nn_key(dist_to(p, sxy, sz), __float_as_uint(p.w))); });
+    }
+    nn = wave_min_u64(t1);
+    const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
+    if (__uint_as_float((unsigned)(nn >> 32)) <= b2 || b2 >= 25.0f) break;     // found, or nothing within DISTANCE_SQ_THRESHOLD is left
+  }
+  return nn;
+}
+
+// ring grid: the 3x3 block of cells around the query, then the 16 cells around it (two cells = 5.25 m cover DISTANCE_SQ_THRESHOLD); per cell
+// the ring keys cid +-1, +-2 (the other rings) and, planar class, cid itself.  Cells that cannot hold anything closer than the class's best so
+// far are skipped.
 template <bool PLANE, int kRows>
-__device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0, int nq, const SeqMeta& m, const GridView& g, int lane, int* row) {
-  const int l = lane & 31, last4 = (lane | 31) << 2;
-  const int qi = qi0 + (lane >> 5);
+__device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index, float sx, float sy, float sz, int closest, int cid, bool want2, bool want3,
+                                          unsigned long long& best2, unsigned long long& best3, int lane, int* lds) {
+  const unsigned hm = (unsigned)(g.H - 1);
+  const float2v sxy = {sx, sy};
+  unsigned long long t2 = best2, t3 = best3;
+  float lim2 = fminf(__uint_as_float((unsigned)(best2 >> 32)), 25.0f), lim3 = fminf(__uint_as_float((unsigned)(best3 >> 32)), 25.0f);
+  if (best2 == ~0ull) lim2 = 25.0f;
+  if (best3 == ~0ull) lim3 = 25.0f;
+  for (int level = 0; level < 2 && (want2 || want3); ++level) {
+    const float rc = kCell2, inv = 1.0f / rc;
+    const int cx = (int)floorf(sx * inv), cy = (int)floorf(sy * inv);
+    const int ncell = level == 0 ? 9 : 16;
+    const bool wo = PLANE ? want3 : want2, ws = PLANE && want2;          // other rings wanted / own ring wanted
+    const int n_other = wo ? 4 * ncell : 0, n_look = n_other + (ws ? ncell : 0);
+    for (int lb = 0; lb < n_look; lb += 64) {
+      const int k = lb + lane;
+      int s0 = 0, cnt = 0;
+      if (k < n_look) {
+        const bool other = k < n_other;
+        const int cc = other ? k >> 2 : k - n_other, ko = k & 3;
+        const int key = other ? cid + ((ko & 1) ? 1 : -1) * ((ko >> 1) + 1) : cid;
+        int ddx, ddy;
+        if (level == 0) { ddx = cc % 3 - 1; ddy = cc / 3 - 1; } else ring2d(2, cc, &ddx, &ddy);
+        const float gx = cell_gap(sx, cx + ddx, rc), gy = cell_gap(sy, cy + ddy, rc);
+        const bool second = PLANE ? !other : true;
+        if (key >= 0 && (gx * gx + gy * gy) * 0.999f <= (second ? lim2 : lim3)) {
+          const unsigned hh = hash3(cx + ddx, cy + ddy, key) & hm;
+          s0 = g.start2[hh];
+          cnt = g.start2[hh + 1] - s0;
+        }
+      }
+      sweep2<false, kRows>(g.sorted2, last_index, s0, cnt, lane, 0, lds, [&](const float4& p, int, bool) {
+        const unsigned wb = __float_as_uint(p.w);
+        consider2<PLANE>(dist_to(p, sxy, sz), (int)(wb & kIdxMask), (int)(wb >> 20) - 1, closest, cid, t2, t3);
+      });
+    }
+    best2 = wave_min_u64(t2);
+    if (PLANE) best3 = wave_min_u64(t3);
+    const float bound = ((float)(level + 1) - 0.01f) * rc, b2 = bound * bound;
+    if (b2 >= 25.0f) break;
+    if (best2 != ~0ull) lim2 = __uint_as_float((unsigned)(best2 >> 32));
+    if (PLANE && best3 != ~0ull) lim3 = __uint_as_float((unsigned)(best3 >> 32));
+    if (best2 != ~0ull && lim2 <= b2) want2 = false;
+    if (PLANE && best3 != ~0ull && lim3 <= b2) want3 = false;
+  }
+}
+
+__device__ __forceinline__ unsigned long long read_u64(unsigned long long v, int src) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+}
+__device__ __forceinline__ float read_f32(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
+template <bool PLANE, int kRows>
+__device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0, int nq, int nt, const GridView& g, int lane, int* lds) {
+  constexpr int kRows1 = (kRows + 1) / 2;                                    // rows of 64 of the one-query tails
+  const int l = lane & 31, hsel = lane >> 5, last4 = (lane | 31) << 2;
+  const int qi = qi0 + hsel;
   const bool qact = qi < nq;
   const int qcap = PLANE ? a.R * 24 : a.R * 12;
   const long long qo = (long long)b * qcap + (qact ? qi : qi0);
@@ -891,147 +1048,74 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
   const float4 sel = (PLANE ? a.sel_flat : a.sel_sharp)[qo];                 // k_transform_queries
   const float frac = raw.w - (float)(int)raw.w;                              // relTime of the point (:116)
   const float4* T = PLANE ? a.surf_last + (long long)b * a.cap : a.corner_last + (long long)b * a.R * 120;
-  const unsigned hm = (unsigned)(g.H - 1);
+  const unsigned hm = (unsigned)(g.H - 1), last_index = (unsigned)(nt - 1);
   const float cell = cell3_of(PLANE ? 1 : 0);
+  const float2v selxy = {sel.x, sel.y};
 
-  // ---- exact 1-NN: the 3x3x3 block of fine cells, its candidates kept as (distance, index | ring)
+  // ---- exact 1-NN: the 3x3x3 block of fine cells of both queries, the candidates kept as (distance, index | ring)
   unsigned long long t1 = ~0ull;
   KeptPair<kRows> kept;
-  kept.act = 0u;
 #pragma unroll
-  for (int u = 0; u < kRows; ++u) { kept.d[u] = 0.f; kept.w[u] = 0u; }
-  auto dist = [&](const float4& p) {
-    const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
-    return (ddx * ddx + ddy * ddy) + ddz * ddz;                              // FLANN's L2_Simple sum = the walk's f32 expression (:322-327)
-  };
-  auto key1 = [](float d, unsigned wb) { return ((unsigned long long)__float_as_uint(d) << 32) | ((wb & kIdxMask) << 12) | (wb >> 20); };
+  for (int u = 0; u < kRows; ++u) kept.k[u] = ~0ull;                             // a distance that fails every test
   {
     const float inv = 1.0f / cell;
     const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv), cz = (int)floorf(sel.z * inv);
     int s0 = 0, cnt = 0;
     if (l < 27 && qact) {
-      const unsigned h = hash3(cx + l % 3 - 1, cy + (l % 9) / 3 - 1, cz + l / 9 - 1) & hm;
-      s0 = g.start3[h];
-      cnt = g.start3[h + 1] - s0;
+      const unsigned hh = hash3(cx + l % 3 - 1, cy + (l % 9) / 3 - 1, cz + l / 9 - 1) & hm;
+      s0 = g.start3[hh];
+      cnt = g.start3[hh + 1] - s0;
     }
-    pair_sweep<kRows>(g.sorted3, s0, cnt, lane, last4, row, [&](const float4& p, bool act, int u, bool first) {
-      const float d = dist(p);
-      const unsigned wb = __float_as_uint(p.w);
-      if (first) { kept.d[u] = d; kept.w[u] = wb; kept.act |= act ? 1u << u : 0u; }
-      const unsigned long long v = key1(d, wb);
-      if (act && v < t1) t1 = v;
+    sweep2<true, kRows>(g.sorted3, last_index, s0, cnt, lane, last4, lds, [&](const float4& p, int u, bool first) {
+      const unsigned long long v = nn_key(dist_to(p, selxy, sel.z), __float_as_uint(p.w));
+      if (first) kept.k[u] = v;
+      take_min(t1, v);
     }, &kept.ok);
   }
   unsigned long long nn = half_min_packed(t1, last4);
   {
     const float bound = (1.0f - 0.01f) * cell;                               // every unvisited point is farther than `bound`
-    bool need = qact && !(nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= bound * bound);
-    if (__ballot(need)) {
-      // expanding cubic shells of coarse cells (at most three steps reach DISTANCE_SQ_THRESHOLD), for the halves that need them
-      const float cellc = cell * kCell3CoarseFactor, invc = 1.0f / cellc;
-      const int ux = (int)floorf(sel.x * invc), uy = (int)floorf(sel.y * invc), uz = (int)floorf(sel.z * invc);
-      for (int r = 1;; ++r) {
-        const int ncell = r == 1 ? 27 : 24 * r * r + 2;
-        const float limit = nn != ~0ull ? fminf(__uint_as_float((unsigned)(nn >> 32)), 25.0f) : 25.0f;
-        for (int cb = 0; cb < ncell; cb += 32) {
-          const int c = cb + l;
-          int s0 = 0, cnt = 0;
-          if (need && c < ncell) {
-            int dx, dy, dz;
-            if (r == 1) { dz = c / 9 - 1; dy = (c % 9) / 3 - 1; dx = c % 3 - 1; }
-            else shell3d(r, c, &dx, &dy, &dz);
-            const float gx = cell_gap(sel.x, ux + dx, cellc), gy = cell_gap(sel.y, uy + dy, cellc), gz = cell_gap(sel.z, uz + dz, cellc);
-            if (((gx * gx + gy * gy) + gz * gz) * 0.999f <= limit) {
-              const unsigned h = hash3(ux + dx, uy + dy, uz + dz) & hm;
-              s0 = g.start3c[h];
-              cnt = g.start3c[h + 1] - s0;
-            }
-          }
-          pair_sweep<kRows>(g.sorted3c, s0, cnt, lane, last4, row, [&](const float4& p, bool act, int, bool) {
-            const unsigned long long v = key1(dist(p), __float_as_uint(p.w));
-            if (act && v < t1) t1 = v;
-          });
-        }
-        nn = half_min_packed(t1, last4);
-        const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
-        if (nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= b2) need = false;
-        if (b2 >= 25.0f || !__ballot(need)) break;                          // nothing within DISTANCE_SQ_THRESHOLD is left
-      }
+    const unsigned long long need = __ballot(qact && !(nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= bound * bound));
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!((need >> (32 * q)) & 1ull)) continue;
+      const unsigned long long r = coarse_shells<kRows1>(g, last_index, cell * kCell3CoarseFactor, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), read_u64(nn, 32 * q), lane, lds);
+      if (hsel == q) nn = r;
     }
   }
 
-  // ---- second / third neighbour (:304-361 / :392-455), window form (ring-sorted clouds only: the caller checked)
+  // ---- second / third neighbour (:304-361 / :392-455)
   const float nnd = __uint_as_float((unsigned)(nn >> 32));
-  const bool has1 = qact && nn != ~0ull && (double)nnd < 25.0;               // DISTANCE_SQ_THRESHOLD (:65,305,393)
+  const bool has1 = qact && nn != ~0ull && nnd < 25.0f;                      // DISTANCE_SQ_THRESHOLD (:65,305,393)
   const int closest = (int)((unsigned)nn >> 12);
   const int cid = (int)((unsigned)nn & 0xfffu) - 1;                          // closestPointScanID (:308,398)
-  unsigned long long t2 = ~0ull, t3 = ~0ull, best2 = ~0ull, best3 = ~0ull;
-  auto consider = [&](float d, unsigned wb, bool act) {
-    const int j = (int)(wb & kIdxMask), key = (int)(wb >> 20) - 1;
-    const bool up = j > closest;
-    bool c2, c3;
-    if (PLANE) { c2 = up ? key <= cid : key >= cid; c3 = !c2; }           // :416-426, :444-454
-    else { c2 = up ? key > cid : key < cid; c3 = false; }                 // :315-316, :341-342 (`continue` on the same side)
-    const bool ok = act && j != closest && (unsigned)(key - cid + 2) <= 4u && (double)d < 25.0;
-    const unsigned seq = up ? (unsigned)(j - closest) : 0x40000000u + (unsigned)(closest - j);
-    const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | seq;
-    if (ok && c2 && v < t2) t2 = v;
-    if (PLANE && ok && c3 && v < t3) t3 = v;
-  };
-  bool want2 = has1, want3 = PLANE && has1;
-  float lim2 = 25.0f, lim3 = 25.0f;
+  unsigned long long best2 = ~0ull, best3 = ~0ull;
   if (__ballot(has1)) {
-    {
+    bool want2 = has1, want3 = PLANE && has1;
+    if (__ballot(has1 && kept.ok)) {
       // the candidates of the fine block are still in registers: neighbours found there within (almost) one cell are final
-      const bool use = has1 && kept.ok;
+      unsigned long long t2 = ~0ull, t3 = ~0ull;
 #pragma unroll
-      for (int u = 0; u < kRows; ++u) consider(kept.d[u], kept.w[u], use && ((kept.act >> u) & 1u));
-      best2 = half_min_packed(t2, last4);
-      if (PLANE) best3 = half_min_packed(t3, last4);
-      const float bound = (1.0f - 0.01f) * cell, b2 = bound * bound;
-      if (best2 != ~0ull) lim2 = __uint_as_float((unsigned)(best2 >> 32));
-      if (PLANE && best3 != ~0ull) lim3 = __uint_as_float((unsigned)(best3 >> 32));
-      if (use && best2 != ~0ull && lim2 <= b2) want2 = false;
-      if (use && PLANE && best3 != ~0ull && lim3 <= b2) want3 = false;
-    }
-    // ring grid: the 3x3 block of cells around the query, then the 16 cells around it (two cells = 5.25 m cover
-    // DISTANCE_SQ_THRESHOLD); per cell the ring keys cid +-1, +-2 (the other rings) and, planar class, cid itself.  Cells that cannot hold
-    // anything closer than the class's best so far are skipped.
-    for (int level = 0; level < 2 && __ballot(want2 || want3); ++level) {
-      const float rc = kCell2, inv = 1.0f / rc;
-      const int cx = (int)floorf(sel.x * inv), cy = (int)floorf(sel.y * inv);
-      const int ncell = level == 0 ? 9 : 16;
-      // look-ups of a half: first the other rings (4 keys per cell), then the own ring (planar class only)
-      const bool wo = PLANE ? want3 : want2, ws = PLANE && want2;          // other rings wanted / own ring wanted
-      const int n_other = wo ? 4 * ncell : 0, n_look = n_other + (ws ? ncell : 0);
-      const int nl0 = __builtin_amdgcn_readlane(n_look, 0), nl1 = __builtin_amdgcn_readlane(n_look, 32), nlmax = nl0 > nl1 ? nl0 : nl1;
-      for (int lb = 0; lb < nlmax; lb += 32) {
-        const int k = lb + l;
-        int s0 = 0, cnt = 0;
-        if (k < n_look) {
-          const bool other = k < n_other;
-          const int cc = other ? k >> 2 : k - n_other, ko = k & 3;
-          const int key = other ? cid + ((ko & 1) ? 1 : -1) * ((ko >> 1) + 1) : cid;
-          int ddx, ddy;
-          if (level == 0) { ddx = cc % 3 - 1; ddy = cc / 3 - 1; } else ring2d(2, cc, &ddx, &ddy);
-          const float gx = cell_gap(sel.x, cx + ddx, rc), gy = cell_gap(sel.y, cy + ddy, rc);
-          const bool second = PLANE ? !other : true;
-          if (key >= 0 && (gx * gx + gy * gy) * 0.999f <= (second ? lim2 : lim3)) {
-            const unsigned h = hash3(cx + ddx, cy + ddy, key) & hm;
-            s0 = g.start2[h];
-            cnt = g.start2[h + 1] - s0;
-          }
-        }
-        pair_sweep<kRows>(g.sorted2, s0, cnt, lane, last4, row, [&](const float4& p, bool act, int, bool) { consider(dist(p), __float_as_uint(p.w), act); });
+      for (int u = 0; u < kRows; ++u) {
+        const unsigned lo = (unsigned)kept.k[u];
+        consider2<PLANE>(__uint_as_float((unsigned)(kept.k[u] >> 32)), (int)(lo >> 12), (int)(lo & 0xfffu) - 1, closest, cid, t2, t3);
       }
-      best2 = half_min_packed(t2, last4);
-      if (PLANE) best3 = half_min_packed(t3, last4);
-      const float bound = ((float)(level + 1) - 0.01f) * rc, b2 = bound * bound;
-      if (b2 >= 25.0f) break;
-      if (best2 != ~0ull) lim2 = __uint_as_float((unsigned)(best2 >> 32));
-      if (PLANE && best3 != ~0ull) lim3 = __uint_as_float((unsigned)(best3 >> 32));
-      if (best2 != ~0ull && lim2 <= b2) want2 = false;
-      if (PLANE && best3 != ~0ull && lim3 <= b2) want3 = false;
+      const bool use = has1 && kept.ok;
+      best2 = half_min_packed(use ? t2 : ~0ull, last4);
+      if (PLANE) best3 = half_min_packed(use ? t3 : ~0ull, last4);
+      const float bound = (1.0f - 0.01f) * cell, b2 = bound * bound;
+      if (best2 != ~0ull && __uint_as_float((unsigned)(best2 >> 32)) <= b2) want2 = false;
+      if (PLANE && best3 != ~0ull && __uint_as_float((unsigned)(best3 >> 32)) <= b2) want3 = false;
+    }
+    const unsigned long long w2 = __ballot(want2), w3 = __ballot(want3);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const bool q2 = (w2 >> (32 * q)) & 1ull, q3 = (w3 >> (32 * q)) & 1ull;
+      if (!(q2 || q3)) continue;
+      unsigned long long r2 = read_u64(best2, 32 * q), r3 = read_u64(best3, 32 * q);
+      ring_grid<PLANE, kRows1>(g, last_index, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), __builtin_amdgcn_readlane(closest, 32 * q),
+                               __builtin_amdgcn_readlane(cid, 32 * q), q2, q3, r2, r3, lane, lds);
+      if (hsel == q) { best2 = r2; best3 = r3; }
     }
   }
   const bool valid = has1 && best2 != ~0ull && (!PLANE || best3 != ~0ull);   // :363 / :457
@@ -1046,9 +1130,7 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
       if (l > 0) {
         x = y = z = 0.f;
         if (valid) {
-          const unsigned long long bw = l == 2 ? best2 : best3;
-          const unsigned seq = (unsigned)bw;
-          const int j = l == 1 ? closest : (seq < 0x40000000u ? closest + (int)seq : closest - (int)(seq - 0x40000000u));
+          const int j = l == 1 ? closest : index_of(l == 2 ? best2 : best3, closest);
           const float4 p = T[j];
           x = p.x; y = p.y; z = p.z;
         }
@@ -1065,7 +1147,7 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
 template <bool PLANE, bool WIDE>
 __global__ __launch_bounds__(64) void k_associate_pair(OdomArgs a) {
   constexpr int kRows = PairRows<PLANE, WIDE>::value;
-  __shared__ int row[kRows * 64];
+  __shared__ int lds[sweep2_lds_ints<kRows>()];
   // XCD-aware work mapping as in k_associate: XCD x works through sequences x, x + 8, ...
   const int lane = threadIdx.x, L = blockIdx.x, xcd = L & 7, slot = L >> 3;
   const int pairs = PLANE ? a.R * 12 : a.R * 6;
@@ -1077,7 +1159,7 @@ __global__ __launch_bounds__(64) void k_associate_pair(OdomArgs a) {
   const GridView g = grid_view(a, b, PLANE ? 1 : 0);
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
   if (g.flags[0] != 0 || g.flags[1] != 0 || nt <= 0) return;                 // k_associate_flagged owns this sequence
-  associate_pair<PLANE, kRows>(a, b, qi0, nq, m, g, lane, row);
+  associate_pair<PLANE, kRows>(a, b, qi0, nq, nt, g, lane, lds);
 }
 
 // Sequences the pair kernel leaves alone: clouds that are not ring-sorted or hold keys / coordinates outside the range the grids are
@@ -1253,7 +1335,7 @@ void launch_transform_queries(const OdomArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL(k_transform_queries<false>, grid, dim3(256), 0, s, a);
 }
 #ifndef ALOAM_ASSOC_PAIR
-#define ALOAM_ASSOC_PAIR 1      // A/B builds: 0 = the one-query-per-wave kernel of rounds 1-3, 1 = two queries per wave for the corner class
+#define ALOAM_ASSOC_PAIR 2      // A/B builds: 0 = the one-query-per-wave kernel of rounds 1-3, 1 = two queries per wave for the corner class
 #endif                          // (measured, batch 1024, two launches: corner 1.048 -> 0.875 ms, planar 2.85 -> 3.03 ms), 2 = for both classes
 void launch_associate(const OdomArgs& a, bool plane, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
