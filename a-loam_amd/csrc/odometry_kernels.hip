@@ -27,6 +27,16 @@
 
 namespace aloam {
 
+// markers in the generated code for tools/isa_phases.py (comments only: no instruction is emitted)
+#define ALOAM_PHASE(name) asm volatile("; ##PHASE " name)
+// debug builds (-DALOAM_ASSOC_STATS): what the association waves actually do, summed over a run (tools/ab_check.py stats)
+#ifdef ALOAM_ASSOC_STATS
+__device__ unsigned long long g_assoc_stats[2][32];
+#define ALOAM_STAT(cls, i, v) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_assoc_stats[cls][i], (unsigned long long)(v)); } while (0)
+#else
+#define ALOAM_STAT(cls, i, v) do { } while (0)
+#endif
+
 // TransformToStart with DISTORTION 0: Identity.slerp(1, q) is exactly +-q (sign flips when w < 0), rotation in
 // f64, result stored back to f32 (reference src/laserOdometry.cpp:111-129).
 __device__ __forceinline__ float4 transform_to_start(const float4& p, const OdomState& st) {
@@ -837,6 +847,12 @@ template <int kRows> struct KeptPair { unsigned long long k[kRows]; bool ok; }; 
 template <int kRows> constexpr int sweep2_lds_ints() { return kRows * 8 + 72; }
 
 typedef float float2v __attribute__((ext_vector_type(2)));
+// bounds of bucket h: start[h] and start[h + 1] by ONE 8-byte load (4-byte aligned: the hardware takes it) at a 32-bit offset from the table
+struct __attribute__((packed, aligned(4))) IntPair { int a, b; };
+__device__ __forceinline__ void bucket_bounds(const int* __restrict__ start, unsigned h, int& s0, int& cnt) {
+  const IntPair v = *reinterpret_cast<const IntPair*>(reinterpret_cast<const char*>(start) + (h << 2));
+  s0 = v.a; cnt = v.b - v.a;
+}
 __device__ __forceinline__ float dist_to(const float4& p, float2v sxy, float sz) {
   const float2v pxy = {p.x, p.y};
   const float2v dxy = pxy - sxy, qxy = dxy * dxy;                             // packed f32: the same two subtractions and products
@@ -844,8 +860,11 @@ __device__ __forceinline__ float dist_to(const float4& p, float2v sxy, float sz)
   return (qxy.x + qxy.y) + ddz * ddz;                                         // FLANN's L2_Simple sum = the walk's f32 expression (:322-327)
 }
 
+#ifndef ALOAM_FINE_EXACT_RADIUS
+#define ALOAM_FINE_EXACT_RADIUS 1   // A/B builds: 0 = 0.99 cells for every query
+#endif
 template <bool HALVES, int kRows, class F>
-__device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsigned last_index, int s0, int cnt, int lane, int last4, int* lds, F&& f, bool* single_round = nullptr) {
+__device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsigned last_index, int s0, int cnt, int lane, int last4, int* lds, F&& f, bool* single_round = nullptr, int* rows_first = nullptr, int stat_cls = 0, int stat_slot = -1) {
   constexpr int W = HALVES ? 32 : 64, LOGW = HALVES ? 5 : 6, kSlots = HALVES ? 2 * kRows : kRows;
   unsigned* marks = reinterpret_cast<unsigned*>(lds);
   int* table = lds + kRows * 8;
@@ -858,9 +877,13 @@ __device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsign
     tmax = t0 > t1 ? t0 : t1;
   } else total = tmax = __builtin_amdgcn_readlane(incl, 63);
   if (single_round) *single_round = total <= kRows * W;
+  if (rows_first) *rows_first = tmax > (kRows - 1) * W ? kRows : (tmax + W - 1) >> LOGW;      // uniform: rows the first round fills
   if (tmax <= 0) return;
   const bool nonempty = cnt > 0;
   const unsigned long long ne = __ballot(nonempty);
+#ifdef ALOAM_ASSOC_STATS
+  if (stat_slot >= 0) { ALOAM_STAT(stat_cls, stat_slot, 1); ALOAM_STAT(stat_cls, stat_slot + 1, __builtin_popcountll(ne)); ALOAM_STAT(stat_cls, stat_slot + 2, HALVES ? __builtin_amdgcn_readlane(incl, 31) + __builtin_amdgcn_readlane(incl, 63) : tmax); ALOAM_STAT(stat_cls, stat_slot + 3, (tmax + W - 1) >> LOGW); }
+#endif
   const int rank_own = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ne >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ne, 0u));
   if (nonempty) table[rank_own] = s0 - (incl - cnt);                          // entry index = position + this
   const int rank0 = HALVES && h ? __builtin_popcount((unsigned)ne) : 0;       // rank of the half's first non-empty bucket
@@ -932,18 +955,46 @@ __device__ __forceinline__ void consider2(float d, int j, int key, int closest, 
   const unsigned seq = (unsigned)(t > nt ? t : nt) | ((unsigned)t & 0x80000000u);   // up: j - closest; down: 2^31 + closest - j
   const bool ok = j != closest && (unsigned)(key - cid + 2) <= 4u && d < 25.0f;     // (double)d < 25.0 (:305,393) is the same test: 25 is an f32 number
   const bool own = key == cid;
-  const unsigned long long v = ((unsigned long long)__float_as_uint(d) << 32) | seq;
+  // a candidate outside its class enters the minimum with distance word ~0: "nothing found" is a key whose HIGH word is ~0 (none() below)
+  const unsigned db = __float_as_uint(d);
   if (PLANE) {
-    if (ok && own) take_min(t2, v);
-    if (ok && !own) take_min(t3, v);
-  } else if (ok && !own) take_min(t2, v);
+    take_min(t2, ((unsigned long long)(ok && own ? db : ~0u) << 32) | seq);
+    take_min(t3, ((unsigned long long)(ok && !own ? db : ~0u) << 32) | seq);
+  } else take_min(t2, ((unsigned long long)(ok && !own ? db : ~0u) << 32) | seq);
 }
+__device__ __forceinline__ bool none(unsigned long long best) { return (unsigned)(best >> 32) == ~0u; }
 __device__ __forceinline__ int index_of(unsigned long long best, int closest) {
   const unsigned seq = (unsigned)best;
   return (seq & 0x80000000u) ? closest - (int)(seq & 0x7fffffffu) : closest + (int)seq;
 }
 
 // ---- the tails, one query at a time on all 64 lanes (state in scalar registers) ----
+// Which cell a lane looks up is a property of the lane: the offsets come from constant tables (one load, no integer division on the vector
+// unit), and the distance from the query to a cell d cells away along an axis is |d| cell + (the distance to the own cell's face on that side
+// - cell - 1 mm), clamped at 0 — the quantity cell_gap() computes, with the query-dependent part hoisted into two wave-uniform numbers per axis.
+struct alignas(16) CellOff2 { int dx, dy; float ax, ay; };                    // ax = |dx| * kCell2
+struct alignas(16) CellOff3 { int dx, dy, dz; int pad; };
+#define ALOAM_C2(x, y) {x, y, (x < 0 ? -x : x) * 2.625f, (y < 0 ? -y : y) * 2.625f}
+__device__ __constant__ CellOff2 kRingCells[24] = {
+    // the eight cells around the own cell
+    ALOAM_C2(-1, -1), ALOAM_C2(0, -1), ALOAM_C2(1, -1), ALOAM_C2(-1, 0), ALOAM_C2(1, 0), ALOAM_C2(-1, 1), ALOAM_C2(0, 1), ALOAM_C2(1, 1),
+    // the sixteen around those
+    ALOAM_C2(-2, -2), ALOAM_C2(-1, -2), ALOAM_C2(0, -2), ALOAM_C2(1, -2), ALOAM_C2(2, -2), ALOAM_C2(-2, 2), ALOAM_C2(-1, 2), ALOAM_C2(0, 2), ALOAM_C2(1, 2), ALOAM_C2(2, 2),
+    ALOAM_C2(-2, -1), ALOAM_C2(-2, 0), ALOAM_C2(-2, 1), ALOAM_C2(2, -1), ALOAM_C2(2, 0), ALOAM_C2(2, 1)};
+#undef ALOAM_C2
+static_assert(kCell2 == 2.625f, "kRingCells holds |d| * kCell2");
+__device__ __constant__ CellOff3 kBlock27[27] = {
+    {-1, -1, -1, 0}, {0, -1, -1, 0}, {1, -1, -1, 0}, {-1, 0, -1, 0}, {0, 0, -1, 0}, {1, 0, -1, 0}, {-1, 1, -1, 0}, {0, 1, -1, 0}, {1, 1, -1, 0},
+    {-1, -1, 0, 0},  {0, -1, 0, 0},  {1, -1, 0, 0},  {-1, 0, 0, 0},  {0, 0, 0, 0},  {1, 0, 0, 0},  {-1, 1, 0, 0},  {0, 1, 0, 0},  {1, 1, 0, 0},
+    {-1, -1, 1, 0},  {0, -1, 1, 0},  {1, -1, 1, 0},  {-1, 0, 1, 0},  {0, 0, 1, 0},  {1, 0, 1, 0},  {-1, 1, 1, 0},  {0, 1, 1, 0},  {1, 1, 1, 0}};
+// the two wave-uniform numbers of an axis: (own cell's upper face - s) - cell - 1 mm and (s - lower face) - cell - 1 mm
+struct AxisGap { float up, dn; };
+__device__ __forceinline__ AxisGap axis_gap_of(float s, int c, float cell) {
+  const float lo = (float)c * cell;
+  return {((lo + cell) - s) - cell - 1e-3f, (s - lo) - cell - 1e-3f};
+}
+__device__ __forceinline__ float axis_gap(int d, float ad_cell, const AxisGap& a) { return fmaxf(ad_cell + (d > 0 ? a.up : a.dn), 0.f); }
+
 // expanding cubic shells of coarse cells around a query whose neighbour is not inside its fine block (at most three steps reach
 // DISTANCE_SQ_THRESHOLD); returns the improved packed 1-NN key
 template <int kRows>
@@ -951,8 +1002,10 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
   const float invc = 1.0f / cellc;
   const float2v sxy = {sx, sy};
   const int ux = (int)floorf(sx * invc), uy = (int)floorf(sy * invc), uz = (int)floorf(sz * invc);
+  const AxisGap ax = axis_gap_of(sx, ux, cellc), ay = axis_gap_of(sy, uy, cellc), az = axis_gap_of(sz, uz, cellc);
   const unsigned hm = (unsigned)(g.H - 1);
   unsigned long long t1 = nn;
+  ALOAM_STAT(0, 28, 1);
   for (int r = 1;; ++r) {
     const int ncell = r == 1 ? 27 : 24 * r * r + 2;
     const float limit = fminf(__uint_as_float((unsigned)(nn >> 32)), 25.0f);
@@ -961,14 +1014,13 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
       int s0 = 0, cnt = 0;
       if (c < ncell) {
         int dx, dy, dz;
-        if (r == 1) { dz = c / 9 - 1; dy = (c % 9) / 3 - 1; dx = c % 3 - 1; }
+        if (r == 1) { const CellOff3 o = kBlock27[c]; dx = o.dx; dy = o.dy; dz = o.dz; }
         else shell3d(r, c, &dx, &dy, &dz);
         // a cell farther away than the best candidate so far (or than DISTANCE_SQ_THRESHOLD) cannot change the answer
-        const float gx = cell_gap(sx, ux + dx, cellc), gy = cell_gap(sy, uy + dy, cellc), gz = cell_gap(sz, uz + dz, cellc);
+        const float gx = axis_gap(dx, fabsf((float)dx) * cellc, ax), gy = axis_gap(dy, fabsf((float)dy) * cellc, ay), gz = axis_gap(dz, fabsf((float)dz) * cellc, az);
         if (((gx * gx + gy * gy) + gz * gz) * 0.999f <= limit) {
           const unsigned hh = hash3(ux + dx, uy + dy, uz + dz) & hm;
-          s0 = g.start3c[hh];
-          cnt = g.start3c[hh + 1] - s0;
+          bucket_bounds(g.start3c, hh, s0, cnt);
         }
       }
       sweep2<false, kRows>(g.sorted3c, last_index, s0, cnt, lane, 0, lds, [&](const float4& p, int, bool) { take_min(t1, nn_key(dist_to(p, sxy, sz), __float_as_uint(p.w))); });
@@ -980,54 +1032,76 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
   return nn;
 }
 
-// ring grid: the 3x3 block of cells around the query, then the 16 cells around it (two cells = 5.25 m cover DISTANCE_SQ_THRESHOLD); per cell
-// the ring keys cid +-1, +-2 (the other rings) and, planar class, cid itself.  Cells that cannot hold anything closer than the class's best so
-// far are skipped.
+// ring grid, three stages: the query's own cell, the eight cells around it, the sixteen around those (two cells = 5.25 m cover
+// DISTANCE_SQ_THRESHOLD); per cell the ring keys cid -1, +1, -2, +2 (the other rings) and, planar class, cid itself.  After a stage everything
+// within the distance to the border of what has been visited is known; cells that cannot hold anything closer than the class's best so far
+// are skipped — the own cell first because its ~50 candidates usually bound the search to one or two of the eight cells (and their ~400 candidates).
+// Measured (batch 1024, two launches; per query pair the planar class sweeps 47 + 95 candidates in 0.98 + 0.85 stages instead of 214 in 1.04):
+// planar class 2.23 -> 2.17 ms, corner class (a third of the candidates, so the extra stage costs more than it prunes) 0.754 -> 0.817 ms.
+#ifndef ALOAM_RING_OWN_CELL_FIRST
+#define ALOAM_RING_OWN_CELL_FIRST PLANE   // A/B builds: 0 = the 3x3 block in one stage, 1 = own cell first for both classes
+#endif
 template <bool PLANE, int kRows>
 __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index, float sx, float sy, float sz, int closest, int cid, bool want2, bool want3,
                                           unsigned long long& best2, unsigned long long& best3, int lane, int* lds) {
+  constexpr bool kOwnFirst = ALOAM_RING_OWN_CELL_FIRST;
   const unsigned hm = (unsigned)(g.H - 1);
   const float2v sxy = {sx, sy};
   unsigned long long t2 = best2, t3 = best3;
-  float lim2 = fminf(__uint_as_float((unsigned)(best2 >> 32)), 25.0f), lim3 = fminf(__uint_as_float((unsigned)(best3 >> 32)), 25.0f);
-  if (best2 == ~0ull) lim2 = 25.0f;
-  if (best3 == ~0ull) lim3 = 25.0f;
-  for (int level = 0; level < 2 && (want2 || want3); ++level) {
-    const float rc = kCell2, inv = 1.0f / rc;
-    const int cx = (int)floorf(sx * inv), cy = (int)floorf(sy * inv);
-    const int ncell = level == 0 ? 9 : 16;
+  float lim2 = !none(best2) ? __uint_as_float((unsigned)(best2 >> 32)) : 25.0f, lim3 = !none(best3) ? __uint_as_float((unsigned)(best3 >> 32)) : 25.0f;
+  const float rc = kCell2, inv = 1.0f / rc;
+  const int cx = (int)floorf(sx * inv), cy = (int)floorf(sy * inv);
+  const AxisGap ax = axis_gap_of(sx, cx, rc), ay = axis_gap_of(sy, cy, rc);
+  const bool track2 = want2;                                             // class 2 open at all (else its minimum is final and not taken again)
+  ALOAM_STAT(PLANE ? 1 : 0, 20, 1); ALOAM_STAT(PLANE ? 1 : 0, 21, want2); ALOAM_STAT(PLANE ? 1 : 0, 22, want3); ALOAM_STAT(PLANE ? 1 : 0, 23, !none(best3) || (!PLANE && !none(best2)));
+  for (int stage = kOwnFirst ? 0 : 1; stage < 3 && (want2 || want3); ++stage) {
+    ALOAM_STAT(PLANE ? 1 : 0, 24 + stage, 1);
+    // look-ups: lane = slot * cells + cell; slots 0..3 = the rings cid -1, +1, -2, +2, slot 4 = cid (planar class).  Stage 1 without the own-cell
+    // stage has 9 cells: the own cell is looked up by the lanes behind the 8 x slots block
     const bool wo = PLANE ? want3 : want2, ws = PLANE && want2;          // other rings wanted / own ring wanted
-    const int n_other = wo ? 4 * ncell : 0, n_look = n_other + (ws ? ncell : 0);
+    const int lc = stage == 0 ? 0 : stage == 1 ? 3 : 4, ncell = 1 << lc, nslot = PLANE ? 5 : 4;
+    const int n_look = ncell * nslot + (stage == 1 && !kOwnFirst ? nslot : 0);
+    ALOAM_PHASE("ring_lookup");
     for (int lb = 0; lb < n_look; lb += 64) {
       const int k = lb + lane;
       int s0 = 0, cnt = 0;
-      if (k < n_look) {
-        const bool other = k < n_other;
-        const int cc = other ? k >> 2 : k - n_other, ko = k & 3;
-        const int key = other ? cid + ((ko & 1) ? 1 : -1) * ((ko >> 1) + 1) : cid;
-        int ddx, ddy;
-        if (level == 0) { ddx = cc % 3 - 1; ddy = cc / 3 - 1; } else ring2d(2, cc, &ddx, &ddy);
-        const float gx = cell_gap(sx, cx + ddx, rc), gy = cell_gap(sy, cy + ddy, rc);
+      const bool centre = k >= ncell * nslot;                            // (stage 1 without the own-cell stage only)
+      const int slot = centre ? k - ncell * nslot : k >> lc;
+      const bool other = slot < 4;
+      if (k < n_look && (other ? wo : ws)) {
+        const int key = cid - 2 + (int)((0x2819u >> (slot * 3)) & 7u);             // slots 0..4: cid -1, +1, -2, +2, 0 (3 bits each, offset by 2)
+        int ddx = 0, ddy = 0;
+        float gx = 0.f, gy = 0.f;
+        if (stage > 0 && !centre) {
+          const CellOff2 o = kRingCells[(stage == 1 ? 0 : 8) + (k & (ncell - 1))];
+          ddx = o.dx; ddy = o.dy;
+          gx = axis_gap(ddx, o.ax, ax); gy = axis_gap(ddy, o.ay, ay);
+        }
         const bool second = PLANE ? !other : true;
         if (key >= 0 && (gx * gx + gy * gy) * 0.999f <= (second ? lim2 : lim3)) {
           const unsigned hh = hash3(cx + ddx, cy + ddy, key) & hm;
-          s0 = g.start2[hh];
-          cnt = g.start2[hh + 1] - s0;
+          bucket_bounds(g.start2, hh, s0, cnt);
         }
       }
+      ALOAM_PHASE("ring_sweep");
       sweep2<false, kRows>(g.sorted2, last_index, s0, cnt, lane, 0, lds, [&](const float4& p, int, bool) {
         const unsigned wb = __float_as_uint(p.w);
         consider2<PLANE>(dist_to(p, sxy, sz), (int)(wb & kIdxMask), (int)(wb >> 20) - 1, closest, cid, t2, t3);
-      });
+      }, nullptr, nullptr, PLANE ? 1 : 0, 8 + 4 * stage);
     }
-    best2 = wave_min_u64(t2);
+    ALOAM_PHASE("ring_mins");
+    if (!PLANE || track2) best2 = wave_min_u64(t2);
     if (PLANE) best3 = wave_min_u64(t3);
-    const float bound = ((float)(level + 1) - 0.01f) * rc, b2 = bound * bound;
+    ALOAM_PHASE("ring_bounds");
+    float bound;                                                          // every point not visited so far is farther than this
+    if (stage == 0) bound = (1.0f - 0.01f) * fmaxf(fminf(fminf(ax.up, ax.dn), fminf(ay.up, ay.dn)) + rc, 0.f);   // nearest face of the own cell, minus 1 mm
+    else bound = ((float)stage - 0.01f) * rc;
+    const float b2 = bound * bound;
     if (b2 >= 25.0f) break;
-    if (best2 != ~0ull) lim2 = __uint_as_float((unsigned)(best2 >> 32));
-    if (PLANE && best3 != ~0ull) lim3 = __uint_as_float((unsigned)(best3 >> 32));
-    if (best2 != ~0ull && lim2 <= b2) want2 = false;
-    if (PLANE && best3 != ~0ull && lim3 <= b2) want3 = false;
+    if (!none(best2)) lim2 = __uint_as_float((unsigned)(best2 >> 32));
+    if (PLANE && !none(best3)) lim3 = __uint_as_float((unsigned)(best3 >> 32));
+    if (!none(best2) && lim2 <= b2) want2 = false;
+    if (PLANE && !none(best3) && lim3 <= b2) want3 = false;
   }
 }
 
@@ -1052,9 +1126,11 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
   const float cell = cell3_of(PLANE ? 1 : 0);
   const float2v selxy = {sel.x, sel.y};
 
+  ALOAM_PHASE("setup");
   // ---- exact 1-NN: the 3x3x3 block of fine cells of both queries, the candidates kept as (distance, index | ring)
   unsigned long long t1 = ~0ull;
   KeptPair<kRows> kept;
+  int kept_rows = 0;                                                         // uniform
 #pragma unroll
   for (int u = 0; u < kRows; ++u) kept.k[u] = ~0ull;                             // a distance that fails every test
   {
@@ -1063,19 +1139,29 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
     int s0 = 0, cnt = 0;
     if (l < 27 && qact) {
       const unsigned hh = hash3(cx + l % 3 - 1, cy + (l % 9) / 3 - 1, cz + l / 9 - 1) & hm;
-      s0 = g.start3[hh];
-      cnt = g.start3[hh + 1] - s0;
+      bucket_bounds(g.start3, hh, s0, cnt);
     }
     sweep2<true, kRows>(g.sorted3, last_index, s0, cnt, lane, last4, lds, [&](const float4& p, int u, bool first) {
       const unsigned long long v = nn_key(dist_to(p, selxy, sel.z), __float_as_uint(p.w));
       if (first) kept.k[u] = v;
       take_min(t1, v);
-    }, &kept.ok);
+    }, &kept.ok, &kept_rows, PLANE ? 1 : 0, 4);
   }
+  ALOAM_PHASE("nn_min");
   unsigned long long nn = half_min_packed(t1, last4);
+  // every point outside the 3x3x3 block is farther away than one cell plus the distance to the nearest face of the query's own cell
+  // (minus the margins of cell_gap): between 1 and 1.5 cells, by query
+  float fine_b2;
   {
-    const float bound = (1.0f - 0.01f) * cell;                               // every unvisited point is farther than `bound`
-    const unsigned long long need = __ballot(qact && !(nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= bound * bound));
+    const float inv = 1.0f / cell;
+    const float lx = floorf(sel.x * inv) * cell, ly = floorf(sel.y * inv) * cell, lz = floorf(sel.z * inv) * cell;
+    const float gap = fminf(fminf(fminf(sel.x - lx, (lx + cell) - sel.x), fminf(sel.y - ly, (ly + cell) - sel.y)), fminf(sel.z - lz, (lz + cell) - sel.z));
+    const float b = (1.0f - 0.01f) * (ALOAM_FINE_EXACT_RADIUS ? cell + (gap > 1e-3f ? gap - 1e-3f : 0.f) : cell);
+    fine_b2 = b * b;
+  }
+  {
+    const float bound2 = fine_b2;
+    const unsigned long long need = __ballot(qact && !(nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= bound2));
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (!((need >> (32 * q)) & 1ull)) continue;
@@ -1084,12 +1170,15 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
     }
   }
 
+  ALOAM_PHASE("classes");
   // ---- second / third neighbour (:304-361 / :392-455)
   const float nnd = __uint_as_float((unsigned)(nn >> 32));
   const bool has1 = qact && nn != ~0ull && nnd < 25.0f;                      // DISTANCE_SQ_THRESHOLD (:65,305,393)
   const int closest = (int)((unsigned)nn >> 12);
   const int cid = (int)((unsigned)nn & 0xfffu) - 1;                          // closestPointScanID (:308,398)
   unsigned long long best2 = ~0ull, best3 = ~0ull;
+  ALOAM_STAT(PLANE ? 1 : 0, 0, 1); ALOAM_STAT(PLANE ? 1 : 0, 1, (int)((__ballot(qact) & 1) + ((__ballot(qact) >> 32) & 1))); ALOAM_STAT(PLANE ? 1 : 0, 2, (int)((__ballot(has1) & 1) + ((__ballot(has1) >> 32) & 1)));
+  ALOAM_STAT(PLANE ? 1 : 0, 3, (int)((__ballot(has1 && kept.ok) & 1) + ((__ballot(has1 && kept.ok) >> 32) & 1)));
   if (__ballot(has1)) {
     bool want2 = has1, want3 = PLANE && has1;
     if (__ballot(has1 && kept.ok)) {
@@ -1097,28 +1186,34 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
       unsigned long long t2 = ~0ull, t3 = ~0ull;
 #pragma unroll
       for (int u = 0; u < kRows; ++u) {
+        if (u >= kept_rows) continue;
         const unsigned lo = (unsigned)kept.k[u];
         consider2<PLANE>(__uint_as_float((unsigned)(kept.k[u] >> 32)), (int)(lo >> 12), (int)(lo & 0xfffu) - 1, closest, cid, t2, t3);
       }
       const bool use = has1 && kept.ok;
       best2 = half_min_packed(use ? t2 : ~0ull, last4);
       if (PLANE) best3 = half_min_packed(use ? t3 : ~0ull, last4);
-      const float bound = (1.0f - 0.01f) * cell, b2 = bound * bound;
-      if (best2 != ~0ull && __uint_as_float((unsigned)(best2 >> 32)) <= b2) want2 = false;
-      if (PLANE && best3 != ~0ull && __uint_as_float((unsigned)(best3 >> 32)) <= b2) want3 = false;
+      const float b2 = fine_b2;
+      if (!none(best2) && __uint_as_float((unsigned)(best2 >> 32)) <= b2) want2 = false;
+      if (PLANE && !none(best3) && __uint_as_float((unsigned)(best3 >> 32)) <= b2) want3 = false;
     }
+    ALOAM_PHASE("ring_tail");
     const unsigned long long w2 = __ballot(want2), w3 = __ballot(want3);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const bool q2 = (w2 >> (32 * q)) & 1ull, q3 = (w3 >> (32 * q)) & 1ull;
       if (!(q2 || q3)) continue;
+#ifdef ALOAM_DEBUG_SKIP_RING
+      continue;                                                              // timing experiments only: wrong results
+#endif
       unsigned long long r2 = read_u64(best2, 32 * q), r3 = read_u64(best3, 32 * q);
       ring_grid<PLANE, kRows1>(g, last_index, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), __builtin_amdgcn_readlane(closest, 32 * q),
                                __builtin_amdgcn_readlane(cid, 32 * q), q2, q3, r2, r3, lane, lds);
       if (hsel == q) { best2 = r2; best3 = r3; }
     }
   }
-  const bool valid = has1 && best2 != ~0ull && (!PLANE || best3 != ~0ull);   // :363 / :457
+  ALOAM_PHASE("record");
+  const bool valid = has1 && !none(best2) && (!PLANE || !none(best3));   // :363 / :457
 
   // ---- the record: lane 0 of the half stores the raw, untransformed point (:365-367 / :460-462), lanes 1.. the neighbours (read from the
   // ring-ordered cloud by index: the grid entries are copies of exactly those points), the next lane the flag and the relTime
@@ -1144,8 +1239,11 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
   }
 }
 
+#ifndef ALOAM_PAIR_OCC
+#define ALOAM_PAIR_OCC                   // A/B builds: e.g. -DALOAM_PAIR_OCC='__attribute__((amdgpu_waves_per_eu(8)))'
+#endif
 template <bool PLANE, bool WIDE>
-__global__ __launch_bounds__(64) void k_associate_pair(OdomArgs a) {
+__global__ __launch_bounds__(64) ALOAM_PAIR_OCC void k_associate_pair(OdomArgs a) {
   constexpr int kRows = PairRows<PLANE, WIDE>::value;
   __shared__ int lds[sweep2_lds_ints<kRows>()];
   // XCD-aware work mapping as in k_associate: XCD x works through sequences x, x + 8, ...
@@ -1379,3 +1477,7 @@ void launch_solve(const OdomArgs& a, hipStream_t s) {
 }
 
 }  // namespace aloam
+
+#ifdef ALOAM_ASSOC_STATS
+extern "C" int aloam_debug_assoc_stats(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(aloam::g_assoc_stats), sizeof(unsigned long long) * 64); }
+#endif

@@ -139,6 +139,16 @@ def run(argv):
     rec["profile"] = np.array(json.dumps({"lib": lib_path, "batch": B, "steps": steps, "mapping": mapping, "wall_s_with_readbacks": wall,
                                           "ms_per_step": {k: v["total_ms"] / steps for k, v in prof.items() if v["launches"]}}))
     np.savez(out_path, **rec)
+    L = binding.lib()
+    if hasattr(L, "aloam_debug_assoc_stats"):                   # -DALOAM_ASSOC_STATS builds: what the association waves did
+        st = (C.c_ulonglong * 64)()
+        L.aloam_debug_assoc_stats(st)
+        names = {0: "pairs", 1: "queries", 2: "has1", 3: "kept_ok", 4: "fine sweeps", 5: "fine buckets", 6: "fine candidates", 7: "fine rows32", 20: "ring calls", 21: "ring want2",
+                 22: "ring want3", 23: "ring had bound", 24: "stage0", 25: "stage1", 26: "stage2", 28: "coarse calls",
+                 8: "s0 sweeps", 9: "s0 buckets", 10: "s0 cand", 11: "s0 rows64", 12: "s1 sweeps", 13: "s1 buckets", 14: "s1 cand", 15: "s1 rows64", 16: "s2 sweeps", 17: "s2 buckets", 18: "s2 cand", 19: "s2 rows64"}
+        for cls in (0, 1):
+            q = max(1, st[cls * 32 + 1])
+            print("corner" if cls == 0 else "plane", {names[i]: round(st[cls * 32 + i] / q, 3) for i in sorted(names)}, "queries", st[cls * 32 + 1])
     gpu.close()
     hip.free(base)
     print(lib_path, "->", out_path, "kernel ms per step:", round(sum(v["total_ms"] for v in prof.values()) / steps, 3))
