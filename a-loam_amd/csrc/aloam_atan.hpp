@@ -11,7 +11,7 @@
 #include <string.h>
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ALOAM_HD __device__ __forceinline__
 ALOAM_HD int aloam_f2i(float f) { return __float_as_int(f); }
 ALOAM_HD float aloam_i2f(int i) { return __int_as_float(i); }

@@ -68,7 +68,8 @@ struct aloam_ctx {
   float4 *d_sel_sharp = nullptr, *d_sel_flat = nullptr;
   // scan-to-map refinement (allocated by aloam_mapping_enable)
   bool map_on = false;
-  long long map_err_reported = 0;    // capacity events (MapSeq.err_steps, vox counters[3]) aloam_synchronize has already returned
+  long long map_err_reported = 0;    // voxel-scratch capacity events (vox counters[3]) aloam_synchronize has already returned
+  std::vector<long long> map_err_seen;   // per sequence: pool capacity events (MapSeq.err_steps) already returned
   float map_line_res = 0.4f, map_plane_res = 0.8f;
   int map_pool = 0, map_H[2] = {0, 0}, map_levels = 0, map_cube_levels = 0, map_tile_cap = 0, map_tile_bound[2] = {0, 0}, map_nsegs_max = 0;
   long long map_key_cap = 0;
@@ -394,19 +395,23 @@ int aloam_synchronize(aloam_ctx* c) {
     // caller that queues many steps and synchronises once still hears about every step that dropped points: reported once, at the
     // first aloam_synchronize after it happened.  The steps themselves have run: poses and map are valid, the points that did not
     // fit were left out of the map.
-    long long total = vc[3] + (vc[1] ? 1 : 0);
+    // Per-sequence deltas against what has already been reported, pool events and voxel-scratch events apart, so the message names a sequence
+    // that dropped points SINCE the last call and says which resource ran out.
+    if ((int)c->map_err_seen.size() != c->B) c->map_err_seen.assign(c->B, 0);
+    long long fresh_pool = 0;
     int first_seq = -1;
     for (int b = 0; b < c->B; ++b) {
-      const int n = ms[b].err_steps + ((ms[b].err & kMapErrPool) ? 1 : 0);
-      if (n > 0 && first_seq < 0) first_seq = b;
-      total += n;
+      const long long n = ms[b].err_steps + ((ms[b].err & kMapErrPool) ? 1 : 0);
+      if (n > c->map_err_seen[b]) { fresh_pool += n - c->map_err_seen[b]; if (first_seq < 0) first_seq = b; }
+      c->map_err_seen[b] = n;
     }
-    if (total > c->map_err_reported) {
-      const long long fresh = total - c->map_err_reported;
-      c->map_err_reported = total;
-      c->err = "mapping: " + std::to_string(fresh) + " (sequence, step) pair(s) since the last aloam_synchronize ran out of " +
-               (first_seq >= 0 ? "map pool (first: sequence " + std::to_string(first_seq) + ")" : std::string("voxel-filter scratch")) +
-               "; the points that did not fit were not inserted (raise pool_points)";
+    const long long vox = vc[3] + (vc[1] ? 1 : 0), fresh_vox = vox > c->map_err_reported ? vox - c->map_err_reported : 0;
+    c->map_err_reported = vox;
+    if (fresh_pool + fresh_vox > 0) {
+      c->err = "mapping, since the last aloam_synchronize:";
+      if (fresh_pool) c->err += " " + std::to_string(fresh_pool) + " (sequence, step) pair(s) ran out of map pool (first: sequence " + std::to_string(first_seq) + ")";
+      if (fresh_vox) c->err += std::string(fresh_pool ? " and" : "") + " " + std::to_string(fresh_vox) + " step(s) ran out of voxel-filter scratch";
+      c->err += "; the points that did not fit were not inserted (raise pool_points)";
       return ALOAM_E_CAPACITY;
     }
   }

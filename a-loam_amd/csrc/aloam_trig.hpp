@@ -16,7 +16,7 @@
 #include <string.h>
 #include <math.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define ALOAM_TRIG_HD __device__ __forceinline__
 ALOAM_TRIG_HD int64_t aloam_d2l(double d) { return __double_as_longlong(d); }
 ALOAM_TRIG_HD double aloam_l2d(int64_t l) { return __longlong_as_double(l); }

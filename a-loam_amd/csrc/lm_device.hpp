@@ -116,6 +116,8 @@ struct LmResult { int iterations, successful, termination, n_a, n_b; double init
 // scalar LM logic redundantly; only the evaluations are distributed.  `eval(with_jac, q, t, acc, &n_a, &n_b)` adds this
 // thread's share of the robustified sums at (q, t): acc[0..20] upper triangle of J^T J, acc[21..26] J^T r, acc[27] cost, and
 // counts the residual blocks of the two factor classes it visited.  q (xyzw) and t are updated in place.
+__device__ __forceinline__ bool all_finite(const double* v, int n) { bool f = true; for (int k = 0; k < n; ++k) f = f && isfinite(v[k]); return f; }
+
 template <int NW = 4, class Eval>
 __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], double t[3], int lm_max_iterations, double* s_red) {
   const double kFunctionTol = 1e-6, kGradientTol = 1e-10, kParameterTol = 1e-8, kMinRelDecrease = 1e-3;
@@ -136,8 +138,8 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
 
   if (n_edges + n_planes == 0) {
     termination = 4;
-  } else if (!isfinite(cost)) {
-    termination = 5;              // Ceres: "Residual and Jacobian evaluation failed" (non-finite residual), parameters untouched
+  } else if (!isfinite(cost) || !all_finite(acc, 27)) {
+    termination = 5;              // Ceres: "Residual and Jacobian evaluation failed" (non-finite residual or Jacobian: J^T J / J^T r not finite), parameters untouched
   } else {
     double H[6][6], g[6], scale[6];
     auto unpack = [&](const double* s) {
@@ -154,7 +156,7 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
       quat_plus(q, ng, qg);
       double mx = 0.0;
       for (int k = 0; k < 4; ++k) mx = fmax(mx, fabs(q[k] - qg[k]));
-      for (int k = 0; k < 3; ++k) mx = fmax(mx, fabs(g[3 + k]));
+      for (int k = 0; k < 3; ++k) { const double tg = t[k] + (-g[3 + k]); mx = fmax(mx, fabs(t[k] - tg)); }   // literally |x - Plus(x, -g)|: quantised by ulp(t) like Ceres' own
       return mx;
     };
     double gmax = gradient_max();

@@ -1548,9 +1548,16 @@ __global__ __launch_bounds__(256) void k_map_reserve(MapArgs a) {
         if (d.cnt + ad > d.cap) {
           int want = 2 * (d.cnt + ad);
           if (want < 256) want = 256;
-          const int off = atomicAdd(&ms.pool_used[cls], want);
-          if (off + want > a.pool_cap) {
-            atomicSub(&ms.pool_used[cls], want);                             // hand the failed reservation back
+          // reserve only what fits (compare-and-swap: a blind add followed by a subtraction on failure would let another thread's successful
+          // reservation start inside the range handed back, and a later one overlap it)
+          int off = atomicAdd(&ms.pool_used[cls], 0);
+          for (;;) {
+            if (off + want > a.pool_cap) { off = -1; break; }
+            const int seen = atomicCAS(&ms.pool_used[cls], off, off + want);
+            if (seen == off) break;
+            off = seen;
+          }
+          if (off < 0) {
             atomicOr(&ms.err, kMapErrPool);
             add[c] = -1;                                                     // the scatter pass skips this cube
           } else {

@@ -46,10 +46,15 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 import numpy as np
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s achievable float4 copy)
+# VALU ceiling: 256 CUs x 4 SIMDs, 2.4 GHz.  The integer / select / DPP mix of these kernels occupies one issue slot of four cycles per
+# wave-instruction (SQ_ACTIVE_INST_VALU, which counts quad-cycles, equals SQ_INSTS_VALU to 1 % on every kernel here); MI355X_MICROARCH.md
+# measures 2 cycles for v_fma_f32 — the rate a pure f32 FMA stream would reach — so both ceilings are printed.
+VALU_SIMDS, VALU_CLK_GHZ = 1024, 2.4
+VALU_PEAK_GINST = VALU_SIMDS * VALU_CLK_GHZ / 4.0
 STAGE_KERNELS = {"map_associate": ["k_map_search<0>", "k_map_search<1>", "k_map_fit<0>", "k_map_fit<1>"],   # a profiled stage = these kernels, once each
                  "map_solve": ["k_map_solve"], "map_register": ["k_map_register"], "map_begin": ["k_map_begin"],
                  "map_grid": ["k_mapgrid_build"], "k_build_grids": ["k_build_grids_fused", "k_build_grids"]}
-RK_NAMES = {"k_associate[plane]": "k_associate<true, false", "k_associate[corner]": "k_associate<false, false",      # profiled name -> prefix of the
+RK_NAMES = {"k_associate[plane]": "k_associate_pair<true, ", "k_associate[corner]": "k_associate_pair<false, ",      # profiled name -> prefix of the
             "k_ring_features": "k_ring_features<", "k_solve": "k_solve<false>"}                                     # kernel name rocprofv3 reports
 
 
@@ -74,7 +79,8 @@ def frame_order(n_frames, n_steps):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=120, help="timed steps of the headline leg (120 x ~9 ms: a timed region above one second); the other legs use min(steps, --extra-steps)")
+    ap.add_argument("--extra-steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="independent sequences per GPU (measured: 256 -> 77 k sweeps/s, 512 -> 86 k, 1024 -> 90 k, 2048 -> 93 k)")
     ap.add_argument("--frames", type=int, default=6, help="stored sweeps per sequence (replayed ping-pong)")
@@ -234,12 +240,59 @@ def roofline_of(prof, steps, B, sensor, mapping):
         except (OSError, ValueError):
             continue
         if pm.get("batch") == B and pm.get("mapping") == bool(mapping) and pm.get("sensor") == sensor:
-            cands = STAGE_KERNELS.get(dname) or [k for k in pm.get("fetch_kib", {}) if k.startswith(RK_NAMES.get(dname, dname + "<")) or k == dname][:1]
-            if cands and all(k in pm.get("fetch_kib", {}) and k in pm.get("write_kib", {}) for k in cands):
+            stale = pm.get("lib_sha256") not in (None, lib_sha256())        # counters of another build of the library are not attached
+            names = lambda dn: STAGE_KERNELS.get(dn) or [k for k in pm.get("fetch_kib", {}) if k.startswith(RK_NAMES.get(dn, dn + "<")) or k == dn][:1]
+            cands = names(dname)
+            if not stale and cands and all(k in pm.get("fetch_kib", {}) and k in pm.get("write_kib", {}) for k in cands):
                 r["traffic"] = round(sum(2.0 * pm["fetch_kib"][k] + pm["write_kib"][k] for k in cands) * 1024.0)
                 r["traffic_source"] = pm.get("source", "profiles/")
+            if stale:
+                r["traffic_note"] = f"profiles/{name} was taken with another build of the library (sha256 {str(pm.get('lib_sha256'))[:12]}): not attached"
+            # instruction-side roofline of the kernels that are bound by VALU issue, not by HBM (the association kernels; SQ counter passes of
+            # the same command): wave-instructions per second against SIMDs x clock / 4
+            sq = pm.get("sq", {})
+            valu = {}
+            for pn in ("k_associate[plane]", "k_associate[corner]", "k_ring_features", "k_classify"):
+                kn = names(pn)
+                if stale or pn not in prof or not prof[pn]["launches"] or not kn or kn[0] not in sq or "SQ_INSTS_VALU" not in sq[kn[0]]:
+                    continue
+                c, ms = sq[kn[0]], prof[pn]["total_ms"] / prof[pn]["launches"]
+                g = c["SQ_INSTS_VALU"] / (ms * 1e-3) / 1e9
+                valu[pn] = {"bound": "valu", "achieved": round(g, 1), "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s", "frac": round(g / VALU_PEAK_GINST, 4),
+                            "frac_of_fma_rate_peak": round(g / (2 * VALU_PEAK_GINST), 4), "valu_instructions_per_launch": c["SQ_INSTS_VALU"], "avg_launch_ms": round(ms, 4),
+                            "busy": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / (VALU_SIMDS * c["avg_us"] * 1e-6 * VALU_CLK_GHZ * 1e9), 4) if c.get("SQ_ACTIVE_INST_VALU") and c.get("avg_us") else None}
+            if valu:
+                r["valu"] = valu
+                if dname in valu:
+                    r["bound"] = "valu"     # the dominant kernel is instruction-bound: `achieved` / `frac` stay its HBM view, r["valu"][kernel] is its ceiling
             break
     return r
+
+
+_LIB_SHA = None
+
+
+def lib_sha256():
+    global _LIB_SHA
+    if _LIB_SHA is None:
+        import hashlib
+        binding = importlib.import_module("a-loam_amd.binding")
+        path = os.environ.get("ALOAM_MI355X_LIB", binding.LIB_PATH)
+        _LIB_SHA = hashlib.sha256(open(path, "rb").read()).hexdigest() if os.path.exists(path) else None
+    return _LIB_SHA
+
+
+def survey_b_scan(cx, wl, n_seq=8):
+    """B_scan = 16 N_in + 32 N + 16 (F_c + L_c + F_s + L_s) + 2 [16 (L_c + L_s + F_c + F_s) + 360 (F_c + F_s)], with the measured
+    sizes of this run (mean over a few sequences after the last timed step)."""
+    binding = importlib.import_module("a-loam_amd.binding")
+    n = min(n_seq, wl.B)
+    L = binding.lib()
+    size = lambda which: float(np.mean([L.aloam_cloud_size(cx.h, b, which) for b in range(n)]))
+    N_in = float(np.mean(wl.counts[:n]))
+    N, Fc, Lc, Fs, Ls = (size(w) for w in (binding.CLOUD_FULL, binding.CLOUD_SHARP, binding.CLOUD_LESS_SHARP, binding.CLOUD_FLAT, binding.CLOUD_LESS_FLAT))
+    b = 16 * N_in + 32 * N + 16 * (Fc + Lc + Fs + Ls) + 2 * (16 * (Lc + Ls + Fc + Fs) + 360 * (Fc + Fs))
+    return {"bytes": round(b), "N_in": round(N_in), "N": round(N), "F_c": round(Fc), "L_c": round(Lc), "F_s": round(Fs), "L_s": round(Ls)}
 
 
 def host_fed(torch, binding, wl, local_rank, steps, warmup, stride=16, contexts=2):
@@ -469,7 +522,9 @@ def main():
     shared = bool(os.environ.get(SHARED_GPU_ENV))
     if shared:
         local_rank %= torch.cuda.device_count()
-    assert torch.cuda.device_count() > local_rank, f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} device(s) visible"
+    if torch.cuda.device_count() <= local_rank:            # before RCCL is asked for a device that does not exist
+        raise SystemExit(f"bench.py rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP device(s) are visible: start one rank per GPU "
+                         f"(--nproc-per-node <= {torch.cuda.device_count()}), or set {SHARED_GPU_ENV}=1 to let ranks share a device (test hook, gloo control plane)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -487,6 +542,7 @@ def main():
         binding.build()
 
     B, T = args.batch, args.frames
+    free0, total_hbm = torch.cuda.mem_get_info(dev)
     wl = Workload(syn, torch, args.sensor, B, T, rank, dev, rough=args.rough)
     NC = max(1, args.contexts)
     assert B % NC == 0, "--batch must be a multiple of --contexts"
@@ -495,6 +551,13 @@ def main():
         for c in ctxs:
             c.mapping_enable(0.4, 0.8, args.map_pool)      # launch/aloam_velodyne_HDL_64.launch: mapping_line / plane_resolution
     elapsed, prof = timed_resident(torch, dist, world, ctxs, wl, args.steps, args.warmup, args.mapping)
+    bscan = survey_b_scan(ctxs[0], wl)
+    free1, _ = torch.cuda.mem_get_info(dev)                # inputs + contexts of THIS rank (of every rank that shares the device under the test hook)
+    try:
+        import psutil
+        rss, host_ram = psutil.Process().memory_info().rss, psutil.virtual_memory().total
+    except ImportError:
+        rss = host_ram = None
     for cx in ctxs:
         cx.close()
     value = world * B * args.steps / elapsed
@@ -504,23 +567,30 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",
            "config": {"workload": wl.describe(args.mapping), "sequences_per_gpu": B, "contexts_per_gpu": NC, "stored_frames": T,
                       "points_per_sweep": wl.NP, "parallelism": f"{world} x independent sequence shards, no collectives"},
-           "roofline": roofline_of(prof, args.steps, B, args.sensor, args.mapping), "input_generation_s": round(wl.gen_s, 2)}
+           "roofline": roofline_of(prof, args.steps, B, args.sensor, args.mapping), "input_generation_s": round(wl.gen_s, 2),
+           "timed_region_s": round(elapsed, 3), "library_sha256": lib_sha256(),
+           "memory": {"hbm_used_bytes": int(free0 - free1), "hbm_bytes_per_sequence": int((free0 - free1) / max(1, B)), "hbm_total_bytes": int(total_hbm),
+                      "host_rss_bytes": rss, "host_ram_bytes": host_ram, "input_bytes": int(B * T * wl.NP * 16)}}
+    # whole-path view with SURVEY.md 8(d)'s B_scan (one figure per sweep, measured sizes) next to the sum of the per-kernel floors above
+    out["roofline"]["survey_b_scan"] = dict(bscan, achieved_gbs=round(value / world * bscan["bytes"] / 1e9, 2), frac=round(value / world * bscan["bytes"] / 1e9 / HBM_PEAK_GBS, 5),
+                                            frac_of_measured_copy_peak=round(value / world * bscan["bytes"] / 6.29e12, 5))
 
     extras = rank == 0 and world == 1 and not args.no_extras
+    xsteps = min(args.steps, args.extra_steps)            # steps of the secondary legs (host-fed, four contexts, configs[2] / [3])
     if extras and NC == 1 and B % 4 == 0:
         # the same steps with the batch split over four contexts (= four HIP streams): tails and launch gaps of one quarter are
         # filled by the others.  Per-kernel events are off in this leg (overlapped intervals do not add up), which is why it is
         # not the headline: `value` and `roofline` above come from one context with events on its own stream.
         c4 = [wl.ctx(binding, B // 4, local_rank) for _ in range(4)]
-        el4, _ = timed_resident(torch, dist, 1, c4, wl, args.steps, args.warmup, False)
+        el4, _ = timed_resident(torch, dist, 1, c4, wl, xsteps, args.warmup, False)
         for cx in c4:
             cx.close()
-        out["overlapped_streams"] = {"contexts": 4, "value": round(B * args.steps / el4, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el4 / args.steps, 4)}
+        out["overlapped_streams"] = {"contexts": 4, "value": round(B * xsteps / el4, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el4 / xsteps, 4), "steps": xsteps}
     if extras:
-        hf = host_fed(torch, binding, wl, local_rank, args.steps, args.warmup, stride=16)
+        hf = host_fed(torch, binding, wl, local_rank, xsteps, args.warmup, stride=16)
         out["value_host_input"] = hf["value"]              # per GPU, PCIe-inclusive, the 16-byte wire format; never the headline
         out["host_input"] = hf
-        out["host_input_xyz12"] = host_fed(torch, binding, wl, local_rank, args.steps, args.warmup, stride=12)
+        out["host_input_xyz12"] = host_fed(torch, binding, wl, local_rank, xsteps, args.warmup, stride=12)
         out["latency"] = latency(binding, wl, local_rank, args.latency_sweeps, mapping=False)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["accuracy"] = accuracy(binding, wl, local_rank)
@@ -533,7 +603,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, wl, rank)
     if extras and not args.mapping and args.sensor == "HDL-64":
         # ---- BASELINE.json configs[2]: the same sweeps with the scan-to-map refinement after every sweep
-        steps2, warm2 = max(4, args.steps // 2), args.warmup
+        steps2, warm2 = max(4, min(args.steps, args.extra_steps)), args.warmup
         cx = wl.ctx(binding, B, local_rank)
         cx.mapping_enable(0.4, 0.8, args.map_pool)
         el2, prof2 = timed_resident(torch, dist, 1, [cx], wl, steps2, warm2, True)

@@ -318,7 +318,9 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
   sm.initial_cost = cost;
   // Ceres' ResidualBlock::Evaluate rejects non-finite residuals / Jacobians: "Residual and Jacobian evaluation failed" -> FAILURE
   // before the first iteration, parameters untouched (e.g. LidarEdgeFactor with a == b: 0 * inf).
-  if (!std::isfinite(cost)) { sm.termination = 5; sm.final_cost = cost; return sm; }
+  bool jac_finite = true;
+  for (double v : J) jac_finite = jac_finite && std::isfinite(v);
+  if (!std::isfinite(cost) || !jac_finite) { sm.termination = 5; sm.final_cost = cost; return sm; }
   // Ceres 1.12 trust_region_minimizer.cc: gradient_max_norm = |x - Plus(x, -g)|_inf, g = J^T r of the unscaled Jacobian in the
   // tangent space (SURVEY.md Appendix A "projected through Plus"); q, t are the current iterate when this is called.
   auto gradient_max = [&](const std::vector<double>& Ju, const std::vector<double>& ru) {
@@ -329,7 +331,7 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
     quat_plus(q, ng, qg);
     double mx = 0.0;
     for (int k = 0; k < 4; ++k) mx = std::max(mx, std::fabs(q[k] - qg[k]));
-    for (int k = 0; k < 3; ++k) mx = std::max(mx, std::fabs(g[3 + k]));      // t - (t - g_t)
+    for (int k = 0; k < 3; ++k) { const double tg = t[k] + (-g[3 + k]); mx = std::max(mx, std::fabs(t[k] - tg)); }   // literally |t - Plus(t, -g_t)|, quantised by ulp(t)
     return mx;
   };
   double gmax = gradient_max(J, r);

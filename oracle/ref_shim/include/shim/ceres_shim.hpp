@@ -315,7 +315,9 @@ inline void Solve(const Solver::Options& o, Problem* problem, Solver::Summary* s
   if (m == 0) { sum->shim_termination = 4; sum->termination_type = CONVERGENCE; return; }
   ev.evaluate(x, &cost, &r, &J);
   sum->initial_cost = cost;
-  if (!std::isfinite(cost)) {   // ResidualBlock::Evaluate's validity check fails: FAILURE before the first iteration, x untouched
+  bool jac_finite = true;
+  for (double v : J) jac_finite = jac_finite && std::isfinite(v);
+  if (!std::isfinite(cost) || !jac_finite) {   // ResidualBlock::Evaluate's validity check (residuals AND Jacobians) fails: FAILURE before the first iteration, x untouched
     sum->final_cost = cost; sum->iterations = 0; sum->shim_termination = 5; sum->termination_type = FAILURE;
     return;
   }

@@ -499,6 +499,41 @@ def test_two_rank_bench_run(binding, tmp_path):
                        "two_ranks": two, "one_rank": one}, f, indent=1)
 
 
+def test_eight_rank_bench_run(binding):
+    """The driver's N = 8 launch shape, as far as a one-GPU box allows: `python bench.py --gpus 8` starts eight ranks (one process each,
+    rendezvous on 127.0.0.1) that share the single device (ALOAM_BENCH_SHARED_GPU: gloo control plane), 16 sequences each, no data-path
+    collective; rank 0 prints n_gpus = 8.  From the memory figures of the line and of a one-rank run: a rank's HBM footprint at the
+    default --batch 1024 and eight ranks' host memory must fit a real 8 x MI355X node (288 GB per GPU; the host's RAM)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--frames", "3", "--no-cpu-baseline", "--no-extras"]
+    env = dict(os.environ, ALOAM_BENCH_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r8 = subprocess.run(base + ["--gpus", "8", "--batch", "16"], env=env, capture_output=True, text=True, timeout=900)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    eight = json.loads(r8.stdout.strip().splitlines()[-1])
+    assert eight["n_gpus"] == 8 and eight["config"]["sequences_per_gpu"] == 16 and eight["scaling"] == "weak"
+    assert "8 x independent sequence shards, no collectives" in eight["config"]["parallelism"]
+    r1 = subprocess.run(base + ["--gpus", "1", "--batch", "128"], env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    one = json.loads(r1.stdout.strip().splitlines()[-1])
+    mem = one["memory"]
+    per_seq = mem["hbm_bytes_per_sequence"]
+    assert 5e6 < per_seq < 60e6, mem                                            # ~14 MB of state + 3 x 2.1 MB of stored sweeps
+    assert per_seq * 1024 + 4e9 < 288e9, mem                                    # a rank at the default batch on its own 288 GB GPU
+    if eight["memory"]["host_rss_bytes"]:
+        assert 8 * eight["memory"]["host_rss_bytes"] < 0.8 * eight["memory"]["host_ram_bytes"], eight["memory"]
+    out_dir = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "eight_rank_shared_gpu.json"), "w") as f:
+            json.dump({"how": "ALOAM_BENCH_SHARED_GPU=1 python bench.py --gpus 8 --batch 16 --steps 4 --warmup 2 --frames 3 --no-cpu-baseline --no-extras (eight ranks sharing ONE MI355X, "
+                              "gloo control plane: a launch-shape and memory check, not a scaling number) next to --gpus 1 --batch 128",
+                       "eight_ranks": eight, "one_rank": one}, f, indent=1)
+
+
 def test_ring_count_lookback_survives_concurrent_streams():
     """k_ring_features workgroups wait for the counts of the rings in front of them (bounded spin, kErrInternal on time-out).  Four
     contexts on four streams with mapping enabled interleave their launches on the device for 200 steps: the run must finish, and

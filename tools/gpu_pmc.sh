@@ -20,14 +20,20 @@ pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_I
 pass sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 cd $R
 python - <<PY
-import json
+import hashlib, json, os
 f = json.load(open("$O/pmc_fetch.json")); w = json.load(open("$O/pmc_write.json"))
+s1 = json.load(open("$O/pmc_sq1.json")); s2 = json.load(open("$O/pmc_sq2.json"))
 args = "$*".split()
+lib = os.environ.get("ALOAM_MI355X_LIB", "$R/a-loam_amd/lib/libaloam_mi355x.so")
+sq = {k: dict({c: v[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if c in v},
+              **{c: s2.get(k, {}).get(c) for c in ("SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_ANY") if s2.get(k, {}).get(c) is not None},
+              avg_us=s2.get(k, {}).get("avg_us", v.get("avg_us"))) for k, v in s1.items()}
 json.dump({"batch": int(args[args.index("--batch") + 1]) if "--batch" in args else 1024, "mapping": "--mapping" in args,
            "sensor": args[args.index("--sensor") + 1] if "--sensor" in args else "HDL-64",
-           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of python bench.py --no-cpu-baseline --steps 3 --warmup 1 $* (tools/gpu_pmc.sh $TAG)",
+           "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / two SQ groups, separate passes of python bench.py --no-cpu-baseline --steps 3 --warmup 1 $* (tools/gpu_pmc.sh $TAG)",
            "fetch_kib": {k: v["FETCH_SIZE"] for k, v in f.items() if "FETCH_SIZE" in v}, "write_kib": {k: v["WRITE_SIZE"] for k, v in w.items() if "WRITE_SIZE" in v},
-           "avg_us": {k: v.get("avg_us") for k, v in f.items()}},
+           "avg_us": {k: v.get("avg_us") for k, v in f.items()}, "sq": sq},
           open("$O/pmc_traffic.json", "w"), indent=1)
 PY
 cat $O/pmc_fetch.md $O/pmc_write.md $O/pmc_sq1.md $O/pmc_sq2.md

@@ -9,8 +9,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def lib_sha256():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "a-loam_amd", "lib", "libaloam_mi355x.so"), "rb").read()).hexdigest()
+
+
 def main(tag, prefix):
     src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+    # one binary for the whole set: the counters, the kernel stats and the bench line must be of the library that is in the tree now
+    here = lib_sha256()
+    line0 = json.loads(open(os.path.join(src, "bench.log")).read().strip().splitlines()[-1])
+    tr0 = json.load(open(os.path.join(src, "pmc_headline", "pmc_traffic.json")))
+    for what, sha in (("bench line", line0.get("library_sha256")), ("counter passes", tr0.get("lib_sha256"))):
+        if sha != here:
+            raise SystemExit(f"refusing to install: the {what} under gpurun_out/{tag} are of library {str(sha)[:12]}, a-loam_amd/lib holds {here[:12]}")
     cp = lambda a, b: shutil.copyfile(os.path.join(src, a), os.path.join(dst, b))
     line = open(os.path.join(src, "bench.log")).read().strip().splitlines()[-1]
     batch = json.loads(line)["config"]["sequences_per_gpu"]
@@ -27,7 +39,7 @@ def main(tag, prefix):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             cp(f"pmc_{cfg}_{c}.md", f"{prefix}_pmc_{c.split('_')[0].lower()}_{cfg}_b{batch}.md")
         fj, wj = (json.load(open(os.path.join(src, f"pmc_{cfg}_{c}.json"))) for c in ("FETCH_SIZE", "WRITE_SIZE"))
-        traffic[cfg] = {"batch": batch, "mapping": cfg == "mapping", "sensor": sensor,
+        traffic[cfg] = {"batch": batch, "mapping": cfg == "mapping", "sensor": sensor, "lib_sha256": here,
                         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 {args} "
                                   f"(tools/gpu_evidence.sh); profiles/{prefix}_pmc_fetch_{cfg}_b{batch}.md, {prefix}_pmc_write_{cfg}_b{batch}.md",
                         "fetch_kib": {k: v["FETCH_SIZE"] for k, v in fj.items() if "FETCH_SIZE" in v}, "write_kib": {k: v["WRITE_SIZE"] for k, v in wj.items() if "WRITE_SIZE" in v},
