@@ -166,8 +166,14 @@ __device__ __forceinline__ unsigned hash3(int a, int b, int c) {
 constexpr int kFusedMaxN = 65535, kFusedMaxH = 16384;
 __host__ __device__ __forceinline__ bool fused_takes(int n, int H) { return n <= kFusedMaxN && H <= kFusedMaxH; }
 
+#ifdef ALOAM_BG_TIMING   // variant builds: one surf workgroup prints the duration of its phases (device timer, 10 ns units)
+#define BG_T(tag) do { __syncthreads(); if (blockIdx.x == 1 && blockIdx.y == 5 && threadIdx.x == 0) { const long long t_ = wall_clock64(); printf("k_build_grids_fused phase %d : %d x10ns (n = %d)\n", tag, (int)(t_ - bg_t_prev), n); bg_t_prev = wall_clock64(); } } while (0)
+#else
+#define BG_T(tag) do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
   constexpr int U = 4;
+  long long bg_t_prev = wall_clock64(); (void)bg_t_prev;
   const int b = blockIdx.y, which = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const SeqMeta m = a.meta[b];
   const int n = which == 0 ? m.n_corner_last : m.n_surf_last;
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
   for (int w = tid; w < 3 * (H / 2); w += 1024) tab[w] = 0u;
   if (tid < 2) s_flag[tid] = 0;
   __syncthreads();
+  BG_T(0);
   const float inv0 = 1.0f / cell3_of(which), inv1 = 1.0f / (cell3_of(which) * kCell3CoarseFactor), inv2 = 1.0f / kCell2;
   const unsigned hm = (unsigned)(H - 1);
   auto buckets = [&](const float4& p, int key, unsigned* h) {
@@ -228,6 +235,7 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
     if (unsorted) atomicOr(&s_flag[1], 1);
   }
   __syncthreads();
+  BG_T(1);
   if (tid < 3) g.flags[tid] = tid == 2 ? ALOAM_COARSE_VIA : s_flag[tid];
   // ---- exclusive scans of the three tables: every thread owns H / 1024 consecutive buckets (= H / 2048 words) of each
   {
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
     }
   }
   __syncthreads();
+  BG_T(2);
   // ---- fill: the three copies of every point from one read
   for (int base = 0; base < n; base += U * 1024) {
     float4 p[U];
@@ -281,6 +290,7 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
       g.sorted2[pos[2]] = e;
     }
   }
+  BG_T(3);
 }
 
 #ifndef ALOAM_BG_WAVES

@@ -554,6 +554,11 @@ __device__ __forceinline__ void radix_sort_run_keys(unsigned* keys, unsigned sho
   }
 }
 
+#ifndef ALOAM_RF_CENTROID_AHEAD
+#define ALOAM_RF_CENTROID_AHEAD 0   // A/B builds: 1 = up to four members of a run loaded ahead (measured: 2.56 -> 2.62 ms, no gain: the phase is not latency-bound at seven workgroups per CU)
+#endif
+// markers in the generated code for tools/isa_phases.py (comments only: no instruction is emitted)
+#define ALOAM_PHASE(name) asm volatile("; ##PHASE " name)
 #ifdef ALOAM_RF_TIMING   // variant builds: one ring workgroup prints the duration of every phase (device timer, 10 ns units; each print itself costs ~130 us)
 #define RF_T(tag) do { __syncthreads(); if (blockIdx.x == 3 && blockIdx.y == 24 && threadIdx.x == 0) { const long long t_ = wall_clock64(); printf("k_ring_features phase %d : %d x10ns\n", tag, (int)(t_ - rf_t_prev)); rf_t_prev = wall_clock64(); } } while (0)
 #else
@@ -609,13 +614,13 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
   for (int it = 0; it < EIT; ++it)
     if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = (K)(((K)myvi[it] << SHIFT) | (K)e); }   // vis is dead: every thread read its share before the barrier
   __syncthreads();
-  RF_T(6);   // run heads + keys
+  RF_T(6); ALOAM_PHASE("after_run_heads");   // run heads + keys
   if (ALOAM_RF_RADIX && sizeof(K) == 4)     // region A behind the keys is free by now: radix counters there, wave totals in s_scan
     radix_sort_run_keys<NPAD>(reinterpret_cast<unsigned*>(smem), reinterpret_cast<unsigned short*>(smem + 4 * NPAD), s_scan + 128, n_runs, SHIFT & 31, key_bits, tid);
   else
     bitonic_sort_keys<K>(rkeys, n_runs, tid);
 
-  RF_T(7);   // sort
+  RF_T(7); ALOAM_PHASE("after_sort");   // sort
   // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
   int n_vox = 0;
   unsigned vmask = 0;
@@ -651,7 +656,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
     if (lane == 0) { s_misc[40] = b0; s_misc[41] = b1; s_misc[42] = b2; s_misc[43] = b3; }
   }
   __syncthreads();
-  RF_T(8);   // voxel heads + gather of the counts in front
+  RF_T(8); ALOAM_PHASE("after_vox_heads_gather");   // voxel heads + gather of the counts in front
   out += s_misc[43];
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
@@ -664,17 +669,37 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
       const K kq = rkeys[q];
       if ((unsigned)(kq >> SHIFT) != vi) break;
       int e = (int)((unsigned)kq & kEMask);
+#if ALOAM_RF_CENTROID_AHEAD
+      // up to four members of the run per round: how far the run goes comes from the flag bytes (LDS), so the four loads are independent of each
+      // other and in flight together instead of one dependent global load per member; the additions keep the input order
+      for (;;) {
+        const bool c1 = e + 1 < L && flags[e + 6], c2 = c1 && e + 2 < L && flags[e + 7], c3 = c2 && e + 3 < L && flags[e + 8];
+        const float4 p0 = cloud[e + 5];
+        float4 p1 = p0, p2 = p0, p3 = p0;
+        if (c1) p1 = cloud[e + 6];
+        if (c2) p2 = cloud[e + 7];
+        if (c3) p3 = cloud[e + 8];
+        sx += p0.x; sy += p0.y; sz += p0.z; si += p0.w;
+        if (c1) { sx += p1.x; sy += p1.y; sz += p1.z; si += p1.w; }
+        if (c2) { sx += p2.x; sy += p2.y; sz += p2.z; si += p2.w; }
+        if (c3) { sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w; }
+        cnt += 1 + (int)c1 + (int)c2 + (int)c3;
+        e += 4;
+        if (!c3 || !(e < L && flags[e + 5])) break;                            // the run stops at the next head or non-member
+      }
+#else
       do {
         const float4 pt = cloud[e + 5];
         sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
         ++cnt;
         ++e;
       } while (e < L && flags[e + 5]);                                        // the run stops at the next head or non-member
+#endif
     }
     const float fc = (float)cnt;
     out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
   }
-  RF_T(9);   // centroids
+  RF_T(9); ALOAM_PHASE("after_centroids");   // centroids
   return n_vox;
 }
 
@@ -793,7 +818,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     __syncthreads();
   }
 
-  RF_T(1);   // curvature
+  RF_T(1); ALOAM_PHASE("after_curvature");   // curvature
   // reach of the neighbour suppression around every point: a pick of i marks i+1 .. i+fw and i-1 .. i-bk (runs of consecutive
   // gap-free steps, at most 5; :316-341).  Packed into the flag byte: bits 2-4 fw, bits 5-7 bk.  The curvature tiles are retired
   // (the loop above ends with a barrier), so region A takes the curvature per local point in the same pass.
@@ -815,7 +840,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   }
   __syncthreads();
 
-  RF_T(2);   // reach + curvature array
+  RF_T(2); ALOAM_PHASE("after_reach");   // reach + curvature array
   // ---- corner / flat selection (:284-390): every sector by its own wave, speculatively without the marks the previous
   // sectors leave on its first five points; those marks only matter if the sector picked one of the marked points, which
   // the second pass detects (and then redoes that sector with the marks) in sector order
@@ -823,7 +848,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
 #pragma unroll 1
   for (int j = __builtin_amdgcn_readfirstlane(wave); j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);   // j in an SGPR: sector bounds, pick positions and spill marks are scalar work
   __syncthreads();
-  RF_T(3);   // first-pass selection
+  RF_T(3); ALOAM_PHASE("after_select1");   // first-pass selection
   if (wave == 0) {
     unsigned carry = (unsigned)s_misc[8];                                    // marks on the (up to 5) points after sector 0
 #pragma unroll 1
@@ -871,7 +896,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     }
   }
 
-  RF_T(4);   // redo, labels, counts
+  RF_T(4); ALOAM_PHASE("after_redo_labels_counts");   // redo, labels, counts
   // ---- labels out (parity tests only) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
   if (a.store_debug) for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
 
@@ -976,7 +1001,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     }
   }
   __syncthreads();
-  RF_T(5);   // bounding box + voxel indices
+  RF_T(5); ALOAM_PHASE("after_bbox_voxidx");   // bounding box + voxel indices
   // 32-bit run keys (voxel index << EB | first element) whenever the voxel box is small enough — most rings: half the LDS
   // traffic and a third fewer VALU instructions in the sort; the 64-bit keys remain for rings whose box has more cells.
   constexpr int EB = NPAD <= 2048 ? 11 : 12;                                  // bits of an element index

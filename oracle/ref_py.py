@@ -105,8 +105,12 @@ def laser_odometry(frames, exe=None, exe_args=()):
         for _ in frames:
             v = rd.f64(14)
             cc, pc = rd.i32(), rd.i32()
-            out.append({"q_w": v[0:4], "t_w": v[4:7], "q_lc": v[7:11], "t_lc": v[11:14], "corner_corr": cc, "plane_corr": pc,
-                        "corner_last": rd.cloud(), "surf_last": rd.cloud()})
+            fr = {"q_w": v[0:4], "t_w": v[4:7], "q_lc": v[7:11], "t_lc": v[11:14], "corner_corr": cc, "plane_corr": pc,
+                  "corner_last": rd.cloud(), "surf_last": rd.cloud()}
+            ne, npl = rd.i32(), rd.i32()                        # correspondences of the frame's last ceres::Solve (constructor arguments of the factors)
+            fr["edges"] = rd.f64(9 * ne).reshape(ne, 9)
+            fr["planes"] = rd.f64(12 * npl).reshape(npl, 12)
+            out.append(fr)
         assert rd.done()
         return out
 

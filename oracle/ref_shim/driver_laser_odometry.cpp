@@ -5,8 +5,12 @@
 //   in : int32 n_frames, then per frame five cloud records: sharp, less_sharp, flat, less_flat, full (/velodyne_cloud_2)
 //   out: per frame 14 float64 (q_w_curr xyzw, t_w_curr, para_q xyzw, para_t), 2 int32 (corner_correspondence,
 //        plane_correspondence of the last outer iteration), then the published /laser_cloud_corner_last and
-//        /laser_cloud_surf_last records (mapping_skip_frame is set to 1 so that every frame is published)
+//        /laser_cloud_surf_last records (mapping_skip_frame is set to 1 so that every frame is published), then the
+//        correspondences of the frame's LAST ceres::Solve: int32 n_edge, n_plane, n_edge x 9 float64 (curr_point, last_point_a,
+//        last_point_b of every LidarEdgeFactor the reference created, :365-381), n_plane x 12 float64 (curr_point, last_point_j, l, m
+//        of every LidarPlaneFactor, :460-479) — read off the functors inside the residual blocks, the reference's source untouched
 #include "ref_io.hpp"
+#include "lidarFactor.hpp"                                                    // the reference's own header (struct members are public)
 
 int ref_node_main(int argc, char** argv);                                     // = main() of the reference node
 extern double para_q[4];                                                      // reference src/laserOdometry.cpp:97-98
@@ -21,6 +25,21 @@ int main(int argc, char** argv) {
   ref_io::must(fin && fout, "cannot open files");
   const int n_frames = ref_io::read_i32(fin);
   int delivered = 0, flushed = 0;
+  std::vector<double> edges, planes;                                          // of the last Solve
+  ceres::shim_solve_hook() = [&](const ceres::Problem& pb) {
+    edges.clear(); planes.clear();
+    auto put = [](std::vector<double>& v, const Eigen::Vector3d& p) { v.push_back(p.x()); v.push_back(p.y()); v.push_back(p.z()); };
+    for (const auto& rb : pb.residuals_) {
+      const std::type_info* ti = rb.cost->shim_functor_type();
+      if (ti && *ti == typeid(LidarEdgeFactor)) {
+        const LidarEdgeFactor* f = static_cast<const LidarEdgeFactor*>(rb.cost->shim_functor());
+        put(edges, f->curr_point); put(edges, f->last_point_a); put(edges, f->last_point_b);
+      } else if (ti && *ti == typeid(LidarPlaneFactor)) {
+        const LidarPlaneFactor* f = static_cast<const LidarPlaneFactor*>(rb.cost->shim_functor());
+        put(planes, f->curr_point); put(planes, f->last_point_j); put(planes, f->last_point_l); put(planes, f->last_point_m);
+      }
+    }
+  };
   auto flush = [&]() {                                                        // results of the frames processed so far
     auto& odom = ref_shim::published<nav_msgs::Odometry>()["/laser_odom_to_init"];
     auto& pc = ref_shim::published<sensor_msgs::PointCloud2>();
@@ -34,6 +53,10 @@ int main(int argc, char** argv) {
       ref_io::must(pc["/laser_cloud_corner_last"].size() == static_cast<size_t>(flushed) + 1, "corner_last not published every frame");
       ref_io::write_cloud(fout, pc["/laser_cloud_corner_last"][flushed]);
       ref_io::write_cloud(fout, pc["/laser_cloud_surf_last"][flushed]);
+      ref_io::write_i32(fout, static_cast<int>(edges.size() / 9)); ref_io::write_i32(fout, static_cast<int>(planes.size() / 12));
+      if (!edges.empty()) ref_io::write_f64(fout, edges.data(), static_cast<int>(edges.size()));
+      if (!planes.empty()) ref_io::write_f64(fout, planes.data(), static_cast<int>(planes.size()));
+      edges.clear(); planes.clear();
       ++flushed;
     }
   };

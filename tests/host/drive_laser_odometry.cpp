@@ -2,6 +2,7 @@
 // oracle/ref_shim/driver_laser_odometry.cpp; para_q / para_t / correspondence counts are read through the C ABI).
 #include "aloam_mi355x.h"
 #include "ref_io.hpp"
+#include <vector>
 
 int node_main(int argc, char** argv);
 aloam_ctx* aloam_node_context();
@@ -35,6 +36,16 @@ int main(int argc, char** argv) {
       ref_io::must(pc["/laser_cloud_corner_last"][flushed].header.frame_id == "/camera", "frame id of the last clouds");
       ref_io::write_cloud(fout, pc["/laser_cloud_corner_last"][flushed]);
       ref_io::write_cloud(fout, pc["/laser_cloud_surf_last"][flushed]);
+      // the factors of the frame's last solve, in the format the reference's driver dumps them (constructor arguments as float64)
+      const int cap_e = 128 * 12, cap_p = 128 * 24;
+      std::vector<float> e(9 * cap_e), p(12 * cap_p);
+      std::vector<int> eq(cap_e), pq(cap_p);
+      int ne = 0, np = 0;
+      if (flushed > 0) ref_io::must(aloam_get_correspondences(aloam_node_context(), 0, e.data(), cap_e, &ne, eq.data(), p.data(), cap_p, &np, pq.data()) == ALOAM_OK, "aloam_get_correspondences");
+      ref_io::write_i32(fout, ne); ref_io::write_i32(fout, np);
+      std::vector<double> de(e.begin(), e.begin() + 9 * ne), dp(p.begin(), p.begin() + 12 * np);
+      if (ne) ref_io::write_f64(fout, de.data(), 9 * ne);
+      if (np) ref_io::write_f64(fout, dp.data(), 12 * np);
       ++flushed;
     }
   };

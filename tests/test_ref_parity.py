@@ -123,11 +123,98 @@ def test_reference_nan_and_range_filter(O):
         assert bits_equal(f[key], ref[key]), key
 
 
+# ---- correspondences as indices (closestPointInd / minPointInd2 / minPointInd3, laserOdometry.cpp:299-483) ------------------------------------
+# Measured: over 20 fresh sequences (HDL-64, VLP-16, rough HDL-64; 27 178 edge and 47 440 planar factors) the canonical
+# voxel summation order of the HIP path flips NO index against the reference's own order; the stated bound below leaves room for one near-tie
+# per ten thousand factors.
+INDEX_FLIPS_PER_10K = 1
+
+
+def _index_tables(corr, feats, last_corner, last_surf):
+    import corr_index
+    e = corr_index.indices(corr[0], feats["sharp"], last_corner)
+    p = corr_index.indices(corr[1], feats["flat"], last_surf)
+    assert (e >= 0).all() and (p >= 0).all(), "a factor's point is not in the cloud it was taken from"
+    return e, p
+
+
+def _assert_index_gap(a, b, ctx):
+    import corr_index
+    r = corr_index.compare(a, b)
+    assert r["differ"] + r["only_a"] + r["only_b"] <= max(1, INDEX_FLIPS_PER_10K * r["both"] // 10000), (ctx, {k: r[k] for k in ("both", "differ", "only_a", "only_b")}, r["which"][:5])
+    return r
+
+
+@pytest.mark.parametrize("path", REF_GOLDENS)
+def test_correspondence_indices_oracle_vs_reference_code(O, path):
+    """The reference's own closestPointInd / minPointInd2 / minPointInd3 (tests/golden: recovered from the factors inside its residual blocks)
+    against the oracle: literal order = identical tables; canonical order (what the HIP path computes) within the stated bound."""
+    g = np.load(path)
+    for canonical in (False, True):
+        orc = O.Oracle(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), canonical_order=canonical)
+        for k in range(_frames(g)):
+            f = orc.scan_register(g[f"scan{k}"])
+            last = (orc.cloud(O.CLOUD_CORNER_LAST), orc.cloud(O.CLOUD_SURF_LAST))
+            orc.odometry_step()
+            if k == 0:
+                continue
+            e, p = _index_tables(orc.correspondences(), f, *last)
+            if canonical:
+                _assert_index_gap(e, g[f"edge_idx{k}"], (path, k, "edge")); _assert_index_gap(p, g[f"plane_idx{k}"], (path, k, "plane"))
+            else:
+                assert np.array_equal(e, g[f"edge_idx{k}"]) and np.array_equal(p, g[f"plane_idx{k}"]), (path, k)
+
+
+def test_correspondence_index_gap_of_the_canonical_order(O, sequence):
+    """How often does the <= 4 ulp summation-order difference of the less-flat centroids flip an index?  Canonical order (HIP path) against
+    literal order (= the reference's code bit for bit, pinned above and by test_live_reference_build_matches_oracle) on fresh sweeps."""
+    tot = {"both": 0, "differ": 0, "only_a": 0, "only_b": 0}
+    for name, seed, kw in (("HDL-64", 210, {"columns": 512}), ("HDL-64", 211, {"columns": 512}), ("VLP-16", 310, {"columns": 900}), ("HDL-64", 410, {"columns": 512, "rough": True})):
+        scans, R, t, model = sequence(name, 4, seed=seed, **kw)
+        oc, ol = (O.Oracle(n_scans=model.n_scans, min_range=model.min_range, canonical_order=c) for c in (True, False))
+        for k, x in enumerate(scans):
+            tabs = []
+            for orc in (oc, ol):
+                f = orc.scan_register(x)
+                last = (orc.cloud(O.CLOUD_CORNER_LAST), orc.cloud(O.CLOUD_SURF_LAST))
+                orc.odometry_step()
+                tabs.append(_index_tables(orc.correspondences(), f, *last) if k else None)
+            if k:
+                for a, b in zip(*tabs):
+                    r = _assert_index_gap(a, b, (name, seed, k))
+                    for key in tot:
+                        tot[key] += r[key]
+    print("index gap canonical vs literal order:", tot)
+    assert tot["both"] > 10000
+
+
+def test_live_reference_correspondences_match_literal_oracle(O, sequence):
+    """Fresh sweeps through the reference's own laserOdometry.cpp (where oracle/_ref exists): the constructor arguments of every LidarEdgeFactor /
+    LidarPlaneFactor it created in the frame's last solve equal the literal-order oracle's records bit for bit, in the same order."""
+    import ref_py
+    if not ref_py.available():
+        pytest.skip("oracle/_ref not built")
+    for name, seed, kw in (("HDL-64", 220, {"columns": 384}), ("VLP-16", 320, {"columns": 700}), ("HDL-64", 420, {"columns": 384, "rough": True})):
+        scans, R, t, model = sequence(name, 3, seed=seed, **kw)
+        reg = ref_py.scan_registration(scans, model.n_scans, model.min_range)
+        odo = ref_py.laser_odometry(reg)
+        orc = O.Oracle(n_scans=model.n_scans, min_range=model.min_range, canonical_order=False)
+        for k, x in enumerate(scans):
+            orc.scan_register(x)
+            orc.odometry_step()
+            if k == 0:
+                continue
+            eo, po, _, _ = orc.correspondences()
+            assert bits_equal(np.asarray(eo, np.float32), odo[k]["edges"].astype(np.float32)), (name, k)
+            assert bits_equal(np.asarray(po, np.float32), odo[k]["planes"].astype(np.float32)), (name, k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", REF_GOLDENS)
 def test_gpu_vs_reference_code(binding, path):
     """The HIP path against the reference's own code: corner / flat picks and the ring-ordered cloud bit-exact, less-flat
-    centroids within 4 ulp (summation order inside a voxel), poses within the north-star tolerance."""
+    centroids within 4 ulp (summation order inside a voxel), the correspondence indices of every factor within the stated (measured: zero)
+    bound, poses within the north-star tolerance."""
     g = np.load(path)
     gpu = binding.Aloam(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), max_points=40000)
     worst_t = worst_r = 0.0
@@ -138,7 +225,14 @@ def test_gpu_vs_reference_code(binding, path):
             assert bits_equal(f[key], g[f"{key}{k}"]), (path, k, key)
         assert bits_equal(f["cloud"][:, 3], g[f"cloud_intensity{k}"])
         assert _close_ulp(f["less_flat"], g[f"less_flat{k}"]) and np.array_equal(f["less_flat"][:, 3].astype(np.int32), g[f"less_flat{k}"][:, 3].astype(np.int32))
+        last = (gpu.cloud(binding.CLOUD_CORNER_LAST), gpu.cloud(binding.CLOUD_SURF_LAST))
         gpu.odometry_step()
+        if k > 0:   # closestPointInd / minPointInd2 / minPointInd3 of the reference's own run, index by index (each side looked up in its own clouds)
+            c = gpu.correspondences()
+            e, pl = _index_tables((c[0], c[1]), f, *last)
+            _assert_index_gap(e, g[f"edge_idx{k}"], (path, k, "edge")); _assert_index_gap(pl, g[f"plane_idx{k}"], (path, k, "plane"))
+            st = gpu.odom_stats()
+            assert abs(st["corner_corr"][1] - int(g[f"corr{k}"][0])) <= 1 and abs(st["plane_corr"][1] - int(g[f"corr{k}"][1])) <= 1, (path, k, st)
         p = gpu.pose()
         worst_t = max(worst_t, np.abs(p["t_lc"] - g[f"t_lc{k}"]).max(), np.linalg.norm(p["t_w"] - g[f"t_w{k}"]))
         worst_r = max(worst_r, quat_angle(p["q_lc"], g[f"q_lc{k}"]), quat_angle(p["q_w"], g[f"q_w{k}"]))
@@ -148,6 +242,7 @@ def test_gpu_vs_reference_code(binding, path):
 
 # ---- scan-to-map refinement (laserMapping.cpp) ---------------------------------------------------------------------
 MAP_GOLDENS = sorted(glob.glob(os.path.join(GOLDEN, "refmap_*.npz")))
+MAP_POINTS_PER_FRAME_BOUND = 2
 
 
 def _map_frames(g):
@@ -194,7 +289,38 @@ def test_mapping_oracle_canonical_order_vs_reference_code(O, path):
             want, got = _cubes_from_golden(g, k, name), orc.map_cubes(cls)
             assert set(want) == set(got)
             n_w, n_g = sum(len(v) for v in want.values()), sum(len(v) for v in got.values())
-            assert abs(n_w - n_g) <= max(2, n_w // 2000), (path, k, name, n_w, n_g)      # a centroid within 1 ulp of a voxel face may re-bin
+            # measured: 4 of 1 731 (frame, cube) populations differ, by one point each, over 60 fresh frames (845 850 map
+            # points): a centroid within an ulp of a voxel face re-bins.  Bound: two points per frame and class.
+            assert abs(n_w - n_g) <= MAP_POINTS_PER_FRAME_BOUND, (path, k, name, n_w, n_g)
+            assert sum(1 for c in want if len(want[c]) != len(got[c])) <= MAP_POINTS_PER_FRAME_BOUND, (path, k, name)
+
+
+def test_mapping_population_gap_of_the_canonical_order(O, sequence):
+    """The same question for the cube map (laserMapping.cpp:737-801): canonical order (HIP path) against literal order (= the reference's code,
+    pinned bit for bit above) through registration + odometry + mapping on fresh sweeps: same cubes, every population within one point, at most
+    MAP_POINTS_PER_FRAME_BOUND differing cubes per frame and class, refined poses within the north-star tolerance."""
+    cubes = differ = 0
+    for name, seed, kw, lr, pr in (("HDL-64", 510, {"columns": 256}, 0.4, 0.8), ("VLP-16", 601, {"columns": 600}, 0.2, 0.4), ("VLP-16", 610, {"columns": 600}, 0.2, 0.4)):
+        scans, R, t, model = sequence(name, 6, seed=seed, **kw)
+        runs = []
+        for canon in (True, False):
+            o = O.Oracle(n_scans=model.n_scans, min_range=model.min_range, canonical_order=canon)
+            o.map_config(lr, pr)
+            per = []
+            for x in scans:
+                o.scan_register(x)
+                po = o.odometry_step()
+                pm = o.mapping_step(po["q_w"], po["t_w"], o.cloud(O.CLOUD_CORNER_LAST), o.cloud(O.CLOUD_SURF_LAST), o.cloud(O.CLOUD_FULL))
+                per.append(([{c: len(v) for c, v in o.map_cubes(cls).items()} for cls in (0, 1)], pm))
+            runs.append(per)
+        for k, ((ca, pa), (cb, pb)) in enumerate(zip(*runs)):
+            assert np.abs(pa["t_w"] - pb["t_w"]).max() < POSE_TOL_M and quat_angle(pa["q_w"], pb["q_w"]) < POSE_TOL_RAD, (name, seed, k)
+            for cls in (0, 1):
+                assert set(ca[cls]) == set(cb[cls]), (name, seed, k, cls)
+                d = [c for c in ca[cls] if ca[cls][c] != cb[cls][c]]
+                assert len(d) <= MAP_POINTS_PER_FRAME_BOUND and all(abs(ca[cls][c] - cb[cls][c]) <= 1 for c in d), (name, seed, k, cls, d)
+                cubes += len(ca[cls]); differ += len(d)
+    print("map population gap canonical vs literal order:", {"cube_states": cubes, "differ_by_one_point": differ})
 
 
 def test_mapping_cube_window_shift_matches_reference_code(O):
@@ -303,20 +429,24 @@ def test_live_distortion_build_matches_oracle(O, sequence):
 @pytest.mark.parametrize("path", DISTORT_GOLDENS)
 def test_gpu_distortion_mode_vs_reference_code(binding, path):
     """aloam_config.distortion on the HIP path against the reference's own DISTORTION 1 build: poses within the north-star
-    tolerance.  Correspondence counts are compared within a handful only, for the same reason the shipped mode's test above
-    compares no counts at all: the reference sums the members of a less-flat voxel in the order its unstable std::sort leaves
-    them, the HIP path in input order (<= 4 ulp in those centroids), and a last-bit difference in a target
-    point can flip a near-tie.  Against the oracle in the same (canonical) order the correspondences are identical:
-    tests/test_gpu_parity.py::test_distortion_mode_matches_oracle."""
+    tolerance, and the correspondence indices of every factor of the reference's run within the stated bound (the reference sums the
+    members of a less-flat voxel in the order its unstable std::sort leaves them, the HIP path in input order: <= 4 ulp in those centroids,
+    which has not flipped an index in any measured sweep).  Against the oracle in the same (canonical) order the
+    correspondences are identical: tests/test_gpu_parity.py::test_distortion_mode_matches_oracle."""
     g = np.load(path)
     gpu = binding.Aloam(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), max_points=40000, distortion=True)
     for k in range(_frames(g)):
         gpu.scan_register(g[f"scan{k}"])
+        f = gpu.features()
+        last = (gpu.cloud(binding.CLOUD_CORNER_LAST), gpu.cloud(binding.CLOUD_SURF_LAST))
         gpu.odometry_step()
         p = gpu.pose()
         assert np.abs(p["t_lc"] - g[f"t_lc{k}"]).max() < POSE_TOL_M and np.linalg.norm(p["t_w"] - g[f"t_w{k}"]) < POSE_TOL_M, (path, k)
         assert quat_angle(p["q_lc"], g[f"q_lc{k}"]) < POSE_TOL_RAD and quat_angle(p["q_w"], g[f"q_w{k}"]) < POSE_TOL_RAD, (path, k)
         st = gpu.odom_stats()
         if k > 0:
-            assert abs(st["corner_corr"][1] - int(g[f"corr{k}"][0])) <= 3 and abs(st["plane_corr"][1] - int(g[f"corr{k}"][1])) <= 3, (path, k, st)
+            c = gpu.correspondences()
+            e, pl = _index_tables((c[0], c[1]), f, *last)
+            _assert_index_gap(e, g[f"edge_idx{k}"], (path, k, "edge")); _assert_index_gap(pl, g[f"plane_idx{k}"], (path, k, "plane"))
+            assert abs(st["corner_corr"][1] - int(g[f"corr{k}"][0])) <= 1 and abs(st["plane_corr"][1] - int(g[f"corr{k}"][1])) <= 1, (path, k, st)
     gpu.close()

@@ -11,6 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import ref_py
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import corr_index
 syn = importlib.import_module("a-loam_amd.synthetic")
 
 CASES = [("ref_vlp16_c600_seed11", "VLP-16", 4, 11, {"columns": 600}), ("ref_hdl64_c256_seed12", "HDL-64", 4, 12, {"columns": 256})]
@@ -33,9 +35,22 @@ def main():
             for key in ("q_lc", "t_lc", "q_w", "t_w"):
                 out[f"{key}{k}"] = odo[k][key]
             out[f"corr{k}"] = np.array([odo[k]["corner_corr"], odo[k]["plane_corr"]])
+            _store_indices(out, k, reg, odo)
         path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path) // 1024, "KiB")
+
+
+def _store_indices(out, k, reg, odo):
+    """closestPointInd / minPointInd2 / minPointInd3 of every factor of the frame's last ceres::Solve (laserOdometry.cpp:299-483), recovered from
+    the constructor arguments inside the reference's residual blocks by exact coordinate look-up in the clouds they came from: rows
+    (query index in the sharp / flat cloud of frame k, indices in laserCloudCornerLast / SurfLast = the less-sharp / less-flat cloud of frame k - 1)."""
+    if k == 0:
+        return
+    e = corr_index.indices(odo[k]["edges"], reg[k]["sharp"], odo[k - 1]["corner_last"])
+    p = corr_index.indices(odo[k]["planes"], reg[k]["flat"], odo[k - 1]["surf_last"])
+    assert (e >= 0).all() and (p >= 0).all() and len(e) == odo[k]["corner_corr"] and len(p) == odo[k]["plane_corr"]
+    out[f"edge_idx{k}"], out[f"plane_idx{k}"] = e.astype(np.int32), p.astype(np.int32)
 
 
 DISTORT_CASES = [("refdistort_hdl64_c256_seed15", "HDL-64", 5, 15, {"columns": 256}), ("refdistort_vlp16_c600_seed16", "VLP-16", 5, 16, {"columns": 600})]
@@ -59,6 +74,7 @@ def main_distortion():
                 out[f"{key}{k}"] = odo[k][key]
                 out[f"plain_{key}{k}"] = plain[k][key]          # DISTORTION 0 on the same sweeps: shows the branch does something
             out[f"corr{k}"] = np.array([odo[k]["corner_corr"], odo[k]["plane_corr"]])
+            _store_indices(out, k, reg, odo)
         path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path) // 1024, "KiB")
