@@ -1653,16 +1653,21 @@ void launch_map_cube_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s)
   hipLaunchKernelGGL(k_map_cube_segments, dim3((a.B * 2 * kMapValidMax + 255) / 256), dim3(256), 0, s, a, v);
 }
 constexpr int kVoxSmallRuns = 8192, kVoxBigRuns = 24576;
+#ifndef ALOAM_VOX_BIG_THREADS
+#define ALOAM_VOX_BIG_THREADS 1024   // the 5 VGPRs this instance spills are values computed before the segment loop and reloaded once per segment (two scratch loads
+                                     // per 40 k-point segment); 768 threads (170 registers) and 512 threads (255) spill the same five: the allocator's choice, not the budget
+#endif
+constexpr int kVoxBigThreads = ALOAM_VOX_BIG_THREADS;
 constexpr size_t vox_lds_bytes(int nt, int capr, int capn) { return (size_t)capr * 6 + (size_t)capn / 8 + 2 * 128 * (size_t)(nt / 64) + sizeof(int) * ((size_t)(capr / nt) * (nt / 64) + 1 + 48) + sizeof(float) * 6 * (nt / 64) + 64; }
-static_assert(vox_lds_bytes(1024, kVoxBigRuns, kVoxBigN) <= 163840, "one workgroup may use the whole 160 KiB of a CU, not more");
+static_assert(vox_lds_bytes(kVoxBigThreads, kVoxBigRuns, kVoxBigN) <= 163840, "one workgroup may use the whole 160 KiB of a CU, not more");
 int prepare_voxel_filter() {     // the 1024-thread instance needs > 64 KiB of dynamic LDS (attribute of the function on the current device)
-  return hipFuncSetAttribute((const void*)k_vox_lds<1024, kVoxBigRuns, kVoxBigN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)vox_lds_bytes(1024, kVoxBigRuns, kVoxBigN)) == hipSuccess ? 0 : -1;
+  return hipFuncSetAttribute((const void*)k_vox_lds<kVoxBigThreads, kVoxBigRuns, kVoxBigN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)vox_lds_bytes(kVoxBigThreads, kVoxBigRuns, kVoxBigN)) == hipSuccess ? 0 : -1;
 }
 void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
   // single-workgroup LDS filter first (grid-stride over the two device-built lists) ...
   const int nsmall = v.n_segs < 4096 ? v.n_segs : 4096, nbig = v.n_segs < 1024 ? v.n_segs : 1024;
-  hipLaunchKernelGGL((k_vox_lds<1024, kVoxBigRuns, kVoxBigN>), dim3(nbig), dim3(1024), vox_lds_bytes(1024, kVoxBigRuns, kVoxBigN), s, v, 1);
+  hipLaunchKernelGGL((k_vox_lds<kVoxBigThreads, kVoxBigRuns, kVoxBigN>), dim3(nbig), dim3(kVoxBigThreads), vox_lds_bytes(kVoxBigThreads, kVoxBigRuns, kVoxBigN), s, v, 1);
   hipLaunchKernelGGL((k_vox_lds<256, kVoxSmallRuns, kVoxSmallN>), dim3(nsmall), dim3(256), vox_lds_bytes(256, kVoxSmallRuns, kVoxSmallN), s, v, 0);
   hipLaunchKernelGGL((k_vox_lds<64, kVoxTinyN, kVoxTinyN>), dim3(v.n_segs < 16384 ? v.n_segs : 16384), dim3(64), vox_lds_bytes(64, kVoxTinyN, kVoxTinyN), s, v, 2);
   // ... then the general path for whatever did not fit: every kernel returns at once when counters[4] == 0 (no tiles)

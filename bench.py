@@ -336,10 +336,16 @@ def host_fed(torch, binding, wl, local_rank, steps, warmup, stride=16, contexts=
             "how": "pinned host batch, one strided H2D copy per context and step on a copy stream, two device slabs each (copy of step k+1 under the kernels of step k), aloam_process_host"}
 
 
-def latency(binding, wl, local_rank, sweeps, mapping):
-    """Single sensor (batch 1), host buffers, blocking calls: what a drop-in ROS node gets per sweep."""
+def latency(binding, wl, local_rank, sweeps, mapping, graph=False):
+    """Single sensor (batch 1), host buffers, blocking calls: what a drop-in ROS node gets per sweep.  graph=False: the odometry step as ~15
+    separate launches instead of one hipGraph launch (ALOAM_GRAPH_MAX_BATCH=0, read by aloam_create)."""
     host = [wl.data[0, k, : wl.counts[0, k]].cpu().numpy() for k in range(wl.T)]
-    cx = wl.ctx(binding, 1, local_rank)
+    prev = os.environ.get("ALOAM_GRAPH_MAX_BATCH")
+    os.environ["ALOAM_GRAPH_MAX_BATCH"] = "8" if graph else "0"
+    try:
+        cx = wl.ctx(binding, 1, local_rank)
+    finally:
+        os.environ.pop("ALOAM_GRAPH_MAX_BATCH") if prev is None else os.environ.__setitem__("ALOAM_GRAPH_MAX_BATCH", prev)
     if mapping:
         cx.mapping_enable(0.4, 0.8, 262144)
     order = frame_order(wl.T, sweeps + 5)
@@ -362,7 +368,8 @@ def latency(binding, wl, local_rank, sweeps, mapping):
     q = lambda v, p: round(1e3 * float(np.percentile(v, p)), 3)
     out = {"sweeps": len(reg), "unit": "ms per sweep", "scan_registration_median": q(reg, 50), "scan_registration_p95": q(reg, 95),
            "odometry_median": q(odo, 50), "odometry_p95": q(odo, 95), "total_median": q(tot, 50), "total_p95": q(tot, 95),
-           "reference_budget_ms_per_stage": 100, "how": "batch 1, pageable host sweep -> aloam_scan_register + aloam_odometry_step + aloam_synchronize per sweep"}
+           "reference_budget_ms_per_stage": 100, "odometry_step_as_one_hipgraph_launch": bool(graph),
+           "how": "batch 1, pageable host sweep -> aloam_scan_register + aloam_odometry_step + aloam_synchronize per sweep"}
     if mapping:
         out["mapping_median"], out["mapping_p95"] = q(mp, 50), q(mp, 95)
     return out
@@ -592,6 +599,7 @@ def main():
         out["host_input"] = hf
         out["host_input_xyz12"] = host_fed(torch, binding, wl, local_rank, xsteps, args.warmup, stride=12)
         out["latency"] = latency(binding, wl, local_rank, args.latency_sweeps, mapping=False)
+        out["latency"]["with_hipgraph_odometry_step"] = {k: v for k, v in latency(binding, wl, local_rank, args.latency_sweeps, mapping=False, graph=True).items() if k.endswith(("median", "p95"))}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["accuracy"] = accuracy(binding, wl, local_rank)
         if not args.rough:     # the same legs on KITTI-shaped irregular sweeps (dropouts, ragged rings, noisy sectors, repeated returns)

@@ -499,6 +499,31 @@ def test_two_rank_bench_run(binding, tmp_path):
                        "two_ranks": two, "one_rank": one}, f, indent=1)
 
 
+def test_odometry_step_graph_replay_matches_separate_launches(binding, sequence, monkeypatch):
+    """With ALOAM_GRAPH_MAX_BATCH >= batch a context replays the ~15 dependent launches of aloam_odometry_step as one hipGraph launch per
+    buffer parity (tried for the ROS shims' batch 1; measured no gain, so off by default).  Same kernels, same arguments: every output must
+    equal, bit for bit, what separate launches compute — over enough sweeps to replay both parities several times."""
+    scans, R, t, model = sequence("HDL-64", 6, seed=31, columns=512)
+    runs = []
+    for env in ("8", "0"):
+        monkeypatch.setenv("ALOAM_GRAPH_MAX_BATCH", env)
+        gpu = _mk(binding, model, batch=2, max_points=max(len(x) for x in scans) + 64)
+        rec = []
+        for x in scans:
+            gpu.scan_register([x, x])
+            gpu.odometry_step()
+            for b in (0, 1):
+                p = gpu.pose(b)
+                c = gpu.correspondences(b)
+                rec.append((np.concatenate([p["q_w"], p["t_w"], p["q_lc"], p["t_lc"]]), c[0].copy(), c[1].copy(), gpu.cloud(binding.CLOUD_SURF_LAST, b)))
+        gpu.close()
+        runs.append(rec)
+    assert len(runs[0]) == len(runs[1]) == 12
+    for a, b in zip(*runs):
+        for x, y in zip(a, b):
+            assert bits_equal(x, y)
+
+
 def test_eight_rank_bench_run(binding):
     """The driver's N = 8 launch shape, as far as a one-GPU box allows: `python bench.py --gpus 8` starts eight ranks (one process each,
     rendezvous on 127.0.0.1) that share the single device (ALOAM_BENCH_SHARED_GPU: gloo control plane), 16 sequences each, no data-path
