@@ -942,6 +942,9 @@ __device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsign
   }
 }
 
+#ifndef ALOAM_PAIR_TAILS
+#define ALOAM_PAIR_TAILS 1           // A/B builds: 0 = the tails always one query at a time
+#endif
 #ifndef ALOAM_PAIR_ROWS_PLANE
 #define ALOAM_PAIR_ROWS_PLANE 6      // rows of 32 candidates per half in flight / kept (A/B builds)
 #endif
@@ -1005,10 +1008,24 @@ __device__ __forceinline__ AxisGap axis_gap_of(float s, int c, float cell) {
 }
 __device__ __forceinline__ float axis_gap(int d, float ad_cell, const AxisGap& a) { return fmaxf(ad_cell + (d > 0 ? a.up : a.dn), 0.f); }
 
+// The tails exist in two forms: HALVES = false — one query on all 64 lanes, its state wave-uniform (scalar registers); HALVES = true —
+// the two queries of the wave side by side, 32 lanes each, when BOTH need the tail (a quarter of the pairs): one set of look-ups, scans,
+// minima and bounds for two queries.  (One query alone on half-width rows would need twice the rows, hence the two forms.)
+template <bool HALVES> __device__ __forceinline__ unsigned long long seg_min(unsigned long long v, int last4) { return HALVES ? half_min_packed(v, last4) : wave_min_u64(v); }
+// maximum over the queries of the wave of a per-query look-up count (uniform)
+template <bool HALVES> __device__ __forceinline__ int seg_max_count(int n) {
+  if (!HALVES) return __builtin_amdgcn_readfirstlane(n);
+  const int a = __builtin_amdgcn_readlane(n, 0), b = __builtin_amdgcn_readlane(n, 32);
+  return a > b ? a : b;
+}
+
 // expanding cubic shells of coarse cells around a query whose neighbour is not inside its fine block (at most three steps reach
-// DISTANCE_SQ_THRESHOLD); returns the improved packed 1-NN key
-template <int kRows>
-__device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, unsigned last_index, float cellc, float sx, float sy, float sz, unsigned long long nn, int lane, int* lds) {
+// DISTANCE_SQ_THRESHOLD); returns the improved packed 1-NN key.  `need`: this query takes part (HALVES: the other may be done already)
+template <int kRows, bool HALVES>
+__device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, unsigned last_index, float cellc, float sx, float sy, float sz, unsigned long long nn, bool need,
+                                                            int lane, int last4, int* lds) {
+  constexpr int W = HALVES ? 32 : 64;
+  const int l = lane & (W - 1);
   const float invc = 1.0f / cellc;
   const float2v sxy = {sx, sy};
   const int ux = (int)floorf(sx * invc), uy = (int)floorf(sy * invc), uz = (int)floorf(sz * invc);
@@ -1019,10 +1036,10 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
   for (int r = 1;; ++r) {
     const int ncell = r == 1 ? 27 : 24 * r * r + 2;
     const float limit = fminf(__uint_as_float((unsigned)(nn >> 32)), 25.0f);
-    for (int cb = 0; cb < ncell; cb += 64) {
-      const int c = cb + lane;
+    for (int cb = 0; cb < ncell; cb += W) {
+      const int c = cb + l;
       int s0 = 0, cnt = 0;
-      if (c < ncell) {
+      if (need && c < ncell) {
         int dx, dy, dz;
         if (r == 1) { const CellOff3 o = kBlock27[c]; dx = o.dx; dy = o.dy; dz = o.dz; }
         else shell3d(r, c, &dx, &dy, &dz);
@@ -1033,11 +1050,12 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
           bucket_bounds(g.start3c, hh, s0, cnt);
         }
       }
-      sweep2<false, kRows>(g.sorted3c, last_index, s0, cnt, lane, 0, lds, [&](const float4& p, int, bool) { take_min(t1, nn_key(dist_to(p, sxy, sz), __float_as_uint(p.w))); });
+      sweep2<HALVES, kRows>(g.sorted3c, last_index, s0, cnt, lane, last4, lds, [&](const float4& p, int, bool) { take_min(t1, nn_key(dist_to(p, sxy, sz), __float_as_uint(p.w))); });
     }
-    nn = wave_min_u64(t1);
+    nn = seg_min<HALVES>(t1, last4);
     const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
-    if (__uint_as_float((unsigned)(nn >> 32)) <= b2 || b2 >= 25.0f) break;     // found, or nothing within DISTANCE_SQ_THRESHOLD is left
+    if (__uint_as_float((unsigned)(nn >> 32)) <= b2) need = false;             // found
+    if (b2 >= 25.0f || !__ballot(need)) break;                                 // nothing within DISTANCE_SQ_THRESHOLD is left / every query is served
   }
   return nn;
 }
@@ -1051,10 +1069,12 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
 #ifndef ALOAM_RING_OWN_CELL_FIRST
 #define ALOAM_RING_OWN_CELL_FIRST PLANE   // A/B builds: 0 = the 3x3 block in one stage, 1 = own cell first for both classes
 #endif
-template <bool PLANE, int kRows>
+template <bool PLANE, int kRows, bool HALVES>
 __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index, float sx, float sy, float sz, int closest, int cid, bool want2, bool want3,
-                                          unsigned long long& best2, unsigned long long& best3, int lane, int* lds) {
+                                          unsigned long long& best2, unsigned long long& best3, int lane, int last4, int* lds) {
   constexpr bool kOwnFirst = ALOAM_RING_OWN_CELL_FIRST;
+  constexpr int W = HALVES ? 32 : 64;
+  const int l = lane & (W - 1);
   const unsigned hm = (unsigned)(g.H - 1);
   const float2v sxy = {sx, sy};
   unsigned long long t2 = best2, t3 = best3;
@@ -1062,9 +1082,9 @@ __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index
   const float rc = kCell2, inv = 1.0f / rc;
   const int cx = (int)floorf(sx * inv), cy = (int)floorf(sy * inv);
   const AxisGap ax = axis_gap_of(sx, cx, rc), ay = axis_gap_of(sy, cy, rc);
-  const bool track2 = want2;                                             // class 2 open at all (else its minimum is final and not taken again)
+  const bool track2 = __ballot(want2) != 0ull;                          // class 2 open at all (else its minimum is final and not taken again)
   ALOAM_STAT(PLANE ? 1 : 0, 20, 1); ALOAM_STAT(PLANE ? 1 : 0, 21, want2); ALOAM_STAT(PLANE ? 1 : 0, 22, want3); ALOAM_STAT(PLANE ? 1 : 0, 23, !none(best3) || (!PLANE && !none(best2)));
-  for (int stage = kOwnFirst ? 0 : 1; stage < 3 && (want2 || want3); ++stage) {
+  for (int stage = kOwnFirst ? 0 : 1; stage < 3 && __ballot(want2 || want3); ++stage) {
     ALOAM_STAT(PLANE ? 1 : 0, 24 + stage, 1);
     // look-ups: lane = slot * cells + cell; slots 0..3 = the rings cid -1, +1, -2, +2, slot 4 = cid (planar class).  Stage 1 without the own-cell
     // stage has 9 cells: the own cell is looked up by the lanes behind the 8 x slots block
@@ -1072,8 +1092,8 @@ __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index
     const int lc = stage == 0 ? 0 : stage == 1 ? 3 : 4, ncell = 1 << lc, nslot = PLANE ? 5 : 4;
     const int n_look = ncell * nslot + (stage == 1 && !kOwnFirst ? nslot : 0);
     ALOAM_PHASE("ring_lookup");
-    for (int lb = 0; lb < n_look; lb += 64) {
-      const int k = lb + lane;
+    for (int lb = 0; lb < n_look; lb += W) {
+      const int k = lb + l;
       int s0 = 0, cnt = 0;
       const bool centre = k >= ncell * nslot;                            // (stage 1 without the own-cell stage only)
       const int slot = centre ? k - ncell * nslot : k >> lc;
@@ -1094,20 +1114,20 @@ __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index
         }
       }
       ALOAM_PHASE("ring_sweep");
-      sweep2<false, kRows>(g.sorted2, last_index, s0, cnt, lane, 0, lds, [&](const float4& p, int, bool) {
+      sweep2<HALVES, kRows>(g.sorted2, last_index, s0, cnt, lane, last4, lds, [&](const float4& p, int, bool) {
         const unsigned wb = __float_as_uint(p.w);
         consider2<PLANE>(dist_to(p, sxy, sz), (int)(wb & kIdxMask), (int)(wb >> 20) - 1, closest, cid, t2, t3);
       }, nullptr, nullptr, PLANE ? 1 : 0, 8 + 4 * stage);
     }
     ALOAM_PHASE("ring_mins");
-    if (!PLANE || track2) best2 = wave_min_u64(t2);
-    if (PLANE) best3 = wave_min_u64(t3);
+    if (!PLANE || track2) best2 = seg_min<HALVES>(t2, last4);
+    if (PLANE) best3 = seg_min<HALVES>(t3, last4);
     ALOAM_PHASE("ring_bounds");
+    if (stage == 2) break;                                               // two cells = 5.25 m: everything within DISTANCE_SQ_THRESHOLD has been seen
     float bound;                                                          // every point not visited so far is farther than this
     if (stage == 0) bound = (1.0f - 0.01f) * fmaxf(fminf(fminf(ax.up, ax.dn), fminf(ay.up, ay.dn)) + rc, 0.f);   // nearest face of the own cell, minus 1 mm
     else bound = ((float)stage - 0.01f) * rc;
     const float b2 = bound * bound;
-    if (b2 >= 25.0f) break;
     if (!none(best2)) lim2 = __uint_as_float((unsigned)(best2 >> 32));
     if (PLANE && !none(best3)) lim3 = __uint_as_float((unsigned)(best3 >> 32));
     if (!none(best2) && lim2 <= b2) want2 = false;
@@ -1120,7 +1140,7 @@ __device__ __forceinline__ unsigned long long read_u64(unsigned long long v, int
 }
 __device__ __forceinline__ float read_f32(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
-template <bool PLANE, int kRows>
+template <bool PLANE, int kRows, bool PAIRED_TAILS>
 __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0, int nq, int nt, const GridView& g, int lane, int* lds) {
   constexpr int kRows1 = (kRows + 1) / 2;                                    // rows of 64 of the one-query tails
   const int l = lane & 31, hsel = lane >> 5, last4 = (lane | 31) << 2;
@@ -1171,15 +1191,21 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
   }
   {
     const float bound2 = fine_b2;
-    const unsigned long long need = __ballot(qact && !(nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= bound2));
+    const bool need1 = qact && !(nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= bound2);
+    const unsigned long long need = __ballot(need1);
+    const bool n0 = need & 1ull, n1 = (need >> 32) & 1ull;
+    if (PAIRED_TAILS && n0 && n1) nn = coarse_shells<kRows1, true>(g, last_index, cell * kCell3CoarseFactor, sel.x, sel.y, sel.z, nn, need1, lane, last4, lds);
+    else if (n0 || n1) {
+      const int q = n0 ? 0 : 1;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (!((need >> (32 * q)) & 1ull)) continue;
-      const unsigned long long r = coarse_shells<kRows1>(g, last_index, cell * kCell3CoarseFactor, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), read_u64(nn, 32 * q), lane, lds);
-      if (hsel == q) nn = r;
+      for (int qq = 0; qq < 2; ++qq) {                                       // (both, one after the other, in builds without the paired form)
+        if (PAIRED_TAILS ? qq != q : !((need >> (32 * qq)) & 1ull)) continue;
+        const unsigned long long r = coarse_shells<kRows1, false>(g, last_index, cell * kCell3CoarseFactor, read_f32(sel.x, 32 * qq), read_f32(sel.y, 32 * qq), read_f32(sel.z, 32 * qq),
+                                                                    read_u64(nn, 32 * qq), true, lane, 0, lds);
+        if (hsel == qq) nn = r;
+      }
     }
   }
-
   ALOAM_PHASE("classes");
   // ---- second / third neighbour (:304-361 / :392-455)
   const float nnd = __uint_as_float((unsigned)(nn >> 32));
@@ -1209,17 +1235,21 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
     }
     ALOAM_PHASE("ring_tail");
     const unsigned long long w2 = __ballot(want2), w3 = __ballot(want3);
+    const bool r0 = (w2 | w3) & 1ull, r1 = ((w2 | w3) >> 32) & 1ull;
+    if (PAIRED_TAILS && r0 && r1) ring_grid<PLANE, kRows1, true>(g, last_index, sel.x, sel.y, sel.z, closest, cid, want2, want3, best2, best3, lane, last4, lds);
+    else {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const bool q2 = (w2 >> (32 * q)) & 1ull, q3 = (w3 >> (32 * q)) & 1ull;
-      if (!(q2 || q3)) continue;
+      for (int q = 0; q < 2; ++q) {
+        const bool q2 = (w2 >> (32 * q)) & 1ull, q3 = (w3 >> (32 * q)) & 1ull;
+        if (!(q2 || q3)) continue;
 #ifdef ALOAM_DEBUG_SKIP_RING
-      continue;                                                              // timing experiments only: wrong results
+        continue;                                                              // timing experiments only: wrong results
 #endif
-      unsigned long long r2 = read_u64(best2, 32 * q), r3 = read_u64(best3, 32 * q);
-      ring_grid<PLANE, kRows1>(g, last_index, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), __builtin_amdgcn_readlane(closest, 32 * q),
-                               __builtin_amdgcn_readlane(cid, 32 * q), q2, q3, r2, r3, lane, lds);
-      if (hsel == q) { best2 = r2; best3 = r3; }
+        unsigned long long r2 = read_u64(best2, 32 * q), r3 = read_u64(best3, 32 * q);
+        ring_grid<PLANE, kRows1, false>(g, last_index, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), __builtin_amdgcn_readlane(closest, 32 * q),
+                                        __builtin_amdgcn_readlane(cid, 32 * q), q2, q3, r2, r3, lane, 0, lds);
+        if (hsel == q) { best2 = r2; best3 = r3; }
+      }
     }
   }
   ALOAM_PHASE("record");
@@ -1267,7 +1297,8 @@ __global__ __launch_bounds__(64) ALOAM_PAIR_OCC void k_associate_pair(OdomArgs a
   const GridView g = grid_view(a, b, PLANE ? 1 : 0);
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
   if (g.flags[0] != 0 || g.flags[1] != 0 || nt <= 0) return;                 // k_associate_flagged owns this sequence
-  associate_pair<PLANE, kRows>(a, b, qi0, nq, nt, g, lane, lds);
+  // (128-ring sensors: the paired tails would take the planar class from 79 to 85 registers, six waves per SIMD to five, for their ~1 %)
+  associate_pair<PLANE, kRows, ALOAM_PAIR_TAILS && !WIDE>(a, b, qi0, nq, nt, g, lane, lds);
 }
 
 // Sequences the pair kernel leaves alone: clouds that are not ring-sorted or hold keys / coordinates outside the range the grids are

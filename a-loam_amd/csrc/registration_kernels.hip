@@ -564,10 +564,15 @@ __device__ __forceinline__ void radix_sort_run_keys(unsigned* keys, unsigned sho
 #else
 #define RF_T(tag) do { } while (0)
 #endif
+// cloudLabel (2 sharp, 1 less sharp, 0, -1 flat) shares the per-point flag byte with the reach of the neighbour suppression: bits 0-1 hold the
+// label code (2, 1, 0, 3 = -1), bits 2-7 the reach during the selection and, afterwards, bit 2 the "continues the run of its predecessor" mark of
+// the voxel filter.  One byte array less per ring is what lets EIGHT ring workgroups share a CU's LDS (20.2 KB each) instead of seven.
+__device__ __forceinline__ bool label_is_member(unsigned char f) { return ((f + 1u) & 2u) == 0u; }        // label <= 0: codes 0 and 3
+__device__ __forceinline__ int label_of(unsigned char f) { const int c = f & 3; return c == 3 ? -1 : c; }
 // ---- second half of pcl::VoxelGrid for one ring: run heads -> sort of the run keys -> voxel heads ->
 // centroids in input order.  K = key type (voxel index << SHIFT | first element of the run), see the call site.
 template <int NPAD, typename K, int SHIFT>
-__device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned char* flags, const signed char* label, int* s_scan, int* s_misc,
+__device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned char* flags, int* s_scan, int* s_misc,
                                                const float4* cloud, float4* out, int L, int tid, int lane, int wave,
                                                unsigned long long* lb_lf, int ring, int nrings, unsigned epoch, int* err, int key_bits, long long& rf_t_prev) {
   const unsigned* vis = reinterpret_cast<const unsigned*>(smem);               // region A: voxel index per element [NPAD] ...
@@ -587,10 +592,12 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
     myvi[it] = 0xffffffffu;
     if (e < L) {
       const unsigned vi = vis[e];
-      const bool member = label[e + 5] <= 0;
-      h = member && (e == 0 || label[e + 4] > 0 || vis[e - 1] != vi);
+      const unsigned char fe = flags[e + 5];
+      const bool member = label_is_member(fe);
+      h = member && (e == 0 || !label_is_member(flags[e + 4]) || vis[e - 1] != vi);
       myvi[it] = vi;
-      flags[e + 5] = (unsigned char)(member && !h);                          // the element continues the run of its predecessor
+      flags[e + 5] = (unsigned char)((fe & 3u) | (member && !h ? 4u : 0u));   // bit 2: the element continues the run of its predecessor (label bits stay: the
+                                                                             // neighbour thread may still be reading them)
     }
     const unsigned long long m = __ballot(h);
     hrank[it] = __popcll(m & ((1ull << lane) - 1ull));
@@ -673,7 +680,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
       // up to four members of the run per round: how far the run goes comes from the flag bytes (LDS), so the four loads are independent of each
       // other and in flight together instead of one dependent global load per member; the additions keep the input order
       for (;;) {
-        const bool c1 = e + 1 < L && flags[e + 6], c2 = c1 && e + 2 < L && flags[e + 7], c3 = c2 && e + 3 < L && flags[e + 8];
+        const bool c1 = e + 1 < L && (flags[e + 6] & 4), c2 = c1 && e + 2 < L && (flags[e + 7] & 4), c3 = c2 && e + 3 < L && (flags[e + 8] & 4);
         const float4 p0 = cloud[e + 5];
         float4 p1 = p0, p2 = p0, p3 = p0;
         if (c1) p1 = cloud[e + 6];
@@ -685,7 +692,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
         if (c3) { sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w; }
         cnt += 1 + (int)c1 + (int)c2 + (int)c3;
         e += 4;
-        if (!c3 || !(e < L && flags[e + 5])) break;                            // the run stops at the next head or non-member
+        if (!c3 || !(e < L && (flags[e + 5] & 4))) break;                            // the run stops at the next head or non-member
       }
 #else
       do {
@@ -693,7 +700,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
         sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
         ++cnt;
         ++e;
-      } while (e < L && flags[e + 5]);                                        // the run stops at the next head or non-member
+      } while (e < L && (flags[e + 5] & 4));                                  // the run stops at the next head or non-member
 #endif
     }
     const float fc = (float)cnt;
@@ -732,8 +739,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   // all scratch lives in the dynamic region so its base stays 16-byte aligned (no static __shared__ in front)
   constexpr int FLAG_BYTES = (MAXN + 15) & ~15;
   unsigned char* flags = smem + ((A_BYTES + 15) & ~15);
-  signed char* label = reinterpret_cast<signed char*>(flags + FLAG_BYTES);
-  int* s_scan = reinterpret_cast<int*>(smem + ((A_BYTES + 15) & ~15) + 2 * FLAG_BYTES);
+  int* s_scan = reinterpret_cast<int*>(smem + ((A_BYTES + 15) & ~15) + FLAG_BYTES);
   float (*s_red)[4] = reinterpret_cast<float (*)[4]>(s_scan + 256);
   int* s_misc = reinterpret_cast<int*>(s_scan + 256 + 24);
   // picks of the 6 sectors (local indices), staged in LDS so that the serial picking loop issues no global store:
@@ -799,7 +805,6 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
         cv[it] = ss.x + ss.y + dZ * dZ;
         if (a.store_debug) a.curv[(long long)b * a.cap + start + i] = cv[it];
       }
-      label[i] = 0;
       const f2 cxy = q0 * inv;
       const float fx = floorf(cxy.x), fy = floorf(cxy.y), fz = floorf(z0 * inv);
       const bool okc = fabsf(fx) < 1024.f && fabsf(fy) < 1024.f && fabsf(fz) < 512.f;
@@ -875,8 +880,8 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     const int j = tid / kSlots, slot = tid % kSlots;
     const int nc = s_misc[1 + j] & 0xff, nfl = s_misc[1 + j] >> 8;
     if (slot >= kSharpPerSector) {
-      if (slot < kSharpPerSector + kLessSharpPerSector) { const int q = slot - kSharpPerSector; if (q < nc) label[s_pick[j * kSlots + slot]] = q < kSharpPerSector ? 2 : 1; }
-      else { const int q = slot - kSharpPerSector - kLessSharpPerSector; if (q < nfl) label[s_pick[j * kSlots + slot]] = -1; }
+      if (slot < kSharpPerSector + kLessSharpPerSector) { const int q = slot - kSharpPerSector; if (q < nc) flags[s_pick[j * kSlots + slot]] = q < kSharpPerSector ? 2 : 1; }
+      else { const int q = slot - kSharpPerSector - kLessSharpPerSector; if (q < nfl) flags[s_pick[j * kSlots + slot]] = 3; }
     }
   }
   __syncthreads();
@@ -898,7 +903,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
 
   RF_T(4); ALOAM_PHASE("after_redo_labels_counts");   // redo, labels, counts
   // ---- labels out (parity tests only) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
-  if (a.store_debug) for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = label[i];
+  if (a.store_debug) for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = (int8_t)label_of(flags[i]);
 
   // ---- pcl::VoxelGrid (leaf 0.2) over the less-flat points of this ring (:401-405)
   // Points follow the ring, so consecutive less-flat points mostly share a voxel: the sort works on RUNS of consecutive
@@ -916,7 +921,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
     for (int e = tid; e < L; e += 256) {
       const int i = e + 5;
-      if (label[i] <= 0) {
+      if (label_is_member(flags[i])) {
         const unsigned c = cells[i];
         const int cx = (int)(c & 2047u), cy = (int)((c >> 11) & 2047u), cz = (int)(c >> 22);
         mn[0] = min(mn[0], cx); mx[0] = max(mx[0], cx); mn[1] = min(mn[1], cy); mx[1] = max(mx[1], cy); mn[2] = min(mn[2], cz); mx[2] = max(mx[2], cz);
@@ -941,7 +946,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       for (int e = tid; e < L; e += 256) {
         const int i = e + 5;
         unsigned vi = 0xffffffffu;                                            // not a member (corner-labelled)
-        if (label[i] <= 0) {
+        if (label_is_member(flags[i])) {
           const unsigned c = cells[i];
           const int i0 = (int)(c & 2047u) - minc[0], i1 = (int)((c >> 11) & 2047u) - minc[1], i2 = (int)(c >> 22) - minc[2];
           vi = (unsigned)(i0 + i1 * divc[0] + i2 * divc[0] * divc[1]);
@@ -955,7 +960,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
     for (int e = tid; e < L; e += 256) {
       const int i = e + 5;
-      if (label[i] <= 0) {
+      if (label_is_member(flags[i])) {
         const float4 p = cloud[i];
         mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
         mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
@@ -987,7 +992,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     for (int e = tid; e < L; e += 256) {
       const int i = e + 5;
       unsigned vi = 0xffffffffu;                                              // not a member (corner-labelled)
-      if (label[i] <= 0) {
+      if (label_is_member(flags[i])) {
         if (overflow) vi = (unsigned)e;         // every point its own cell -> output = input, in order
         else {
           const float4 p = cloud[i];
@@ -1009,9 +1014,9 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   if (!ALOAM_RF_KEYS64 && (overflow || cells_in_box <= (1ll << (32 - EB)))) {
     // bits of a voxel index: every index is below cells_in_box (or, in PCL's overflow case, the element number itself)
     const int key_bits = overflow ? EB : (cells_in_box > 1 ? 64 - __clzll(cells_in_box - 1) : 1);
-    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err, key_bits, rf_t_prev);
+    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err, key_bits, rf_t_prev);
   } else
-    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, label, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err, 0, rf_t_prev);
+    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err, 0, rf_t_prev);
   // the picked points go straight to their final place in the three clouds, in the reference's order (ring, sector, pick order;
   // sharp = the first two less-sharp picks, :301-311)
   if (wave == 0) {
@@ -1047,7 +1052,7 @@ size_t ring_features_lds_bytes(int npad) {
   const int maxn = npad + 11;
   const int a_bytes = 8 * npad + 128;
   const int flag_bytes = (maxn + 15) & ~15;
-  return (size_t)((a_bytes + 15) & ~15) + 2 * (size_t)flag_bytes + (256 + 24 + 48) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
+  return (size_t)((a_bytes + 15) & ~15) + (size_t)flag_bytes + (256 + 24 + 48) * sizeof(int) + 6 * 26 * sizeof(short) + 8;
 }
 
 void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s) { hipLaunchKernelGGL(k_find_ends, dim3(a.B), dim3(1024), 0, s, a, d_nin); }

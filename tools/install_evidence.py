@@ -29,6 +29,9 @@ def main(tag, prefix):
     with open(os.path.join(dst, f"{prefix}_bench_b{batch}.json"), "w") as f:
         json.dump(json.loads(line), f, indent=1)
     cp("pytest_gpu.log", f"{prefix}_pytest_gpu.log")
+    for name in ("two_rank_shared_gpu.json", "eight_rank_shared_gpu.json", "launcher_rccl_one_rank.json"):   # written by the -m gpu tests of the same call
+        if os.path.exists(os.path.join(ROOT, "gpurun_out", name)):
+            shutil.copyfile(os.path.join(ROOT, "gpurun_out", name), os.path.join(dst, f"{prefix}_{name}"))
     for cfg in ("headline", "mapping", "rows128"):
         cp(f"kernel_stats_{cfg}.md", f"{prefix}_kernel_stats_{cfg}_b{batch}.md")
     for c in ("fetch", "write", "sq1", "sq2"):

@@ -18,6 +18,12 @@ def main(d, out):
         kt["kernel"] = kt.Kernel_Name.str.extract(r"aloam::(\w+(?:<[^>]*>)?)")
         kt["us"] = (kt.End_Timestamp - kt.Start_Timestamp) / 1e3
         piv = piv.join(kt.groupby("kernel").us.mean().rename("avg_us"))
+        # spread of the dispatch durations, and the two buffer parities apart (even / odd dispatch of a kernel: the last clouds flip every step)
+        kt = kt.sort_values("Start_Timestamp")
+        kt["parity"] = kt.groupby("kernel").cumcount() % 2
+        sp = kt.groupby("kernel").us.agg(min_us="min", median_us="median", max_us="max")
+        par = kt.pivot_table(index="kernel", columns="parity", values="us", aggfunc="mean").rename(columns={0: "even_us", 1: "odd_us"})
+        piv = piv.join(sp).join(par)
     if out.endswith(".md"):   # machine-readable twin for bench.py's roofline.traffic
         import json
         json.dump({k: {c: float(v) for c, v in row.items() if v == v} for k, row in piv.to_dict(orient="index").items()}, open(out[:-3] + ".json", "w"), indent=1)
