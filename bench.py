@@ -240,7 +240,7 @@ def roofline_of(prof, steps, B, sensor, mapping):
         except (OSError, ValueError):
             continue
         if pm.get("batch") == B and pm.get("mapping") == bool(mapping) and pm.get("sensor") == sensor:
-            stale = pm.get("lib_sha256") not in (None, lib_sha256())        # counters of another build of the library are not attached
+            stale = pm.get("lib_sha256") != lib_sha256()                    # counters of another build of the library (or of unknown origin) are not attached
             names = lambda dn: STAGE_KERNELS.get(dn) or [k for k in pm.get("fetch_kib", {}) if k.startswith(RK_NAMES.get(dn, dn + "<")) or k == dn][:1]
             cands = names(dname)
             if not stale and cands and all(k in pm.get("fetch_kib", {}) and k in pm.get("write_kib", {}) for k in cands):
