@@ -110,6 +110,25 @@ def _records(buf: bytes, what: str) -> Iterator[Tuple[Dict[str, bytes], bytes, i
         yield _parse_header(header), data, start
 
 
+def _file_records(f, what: str) -> Iterator[Tuple[Dict[str, bytes], bytes, int]]:
+    """The same over a file object, one record in memory at a time (a KITTI sequence written as a bag is 10 - 20 GB)."""
+    def need(n, start, part):
+        b = f.read(n)
+        if len(b) != n:
+            raise BagError(f"truncated {what}: record {part} cut off at byte {start}")
+        return b
+    while True:
+        start = f.tell()
+        first = f.read(4)
+        if not first:
+            return
+        if len(first) != 4:
+            raise BagError(f"truncated {what}: record length cut off at byte {start}")
+        header = need(struct.unpack("<I", first)[0], start, "header")
+        (dl,) = struct.unpack("<I", need(4, start, "header"))
+        yield _parse_header(header), need(dl, start, "data"), start
+
+
 def _time_ns(v: bytes) -> int:
     secs, nsecs = struct.unpack("<II", v)
     return secs * 1_000_000_000 + nsecs
@@ -117,9 +136,9 @@ def _time_ns(v: bytes) -> int:
 
 def read_messages(path: str, topics: Optional[List[str]] = None) -> Iterator[Tuple[str, str, int, bytes]]:
     """Yields (topic, message type, bag time in ns, serialised message) in file order (= recording order)."""
-    with open(path, "rb") as f:
-        blob = f.read()
-    if not blob.startswith(MAGIC):
+    f = open(path, "rb")
+    if f.read(len(MAGIC)) != MAGIC:
+        f.close()
         raise BagError("not a ROS bag (format 2.0) file")
     conns: Dict[int, Tuple[str, str]] = {}
     want = set(topics) if topics else None
@@ -137,7 +156,15 @@ def read_messages(path: str, topics: Optional[List[str]] = None) -> Iterator[Tup
                 return topic, typ, _time_ns(h["time"]), data
         return None
 
-    for h, data, _ in _records(blob[len(MAGIC):], "bag"):
+    try:
+        yield from _walk(f, handle)
+    finally:
+        f.close()
+
+
+def _walk(f, handle):
+    """Records of the file one at a time: a chunk (and, for bz2, its decompressed form) is the most that is held in memory."""
+    for h, data, _ in _file_records(f, "bag"):
         if "op" not in h:
             raise BagError("record without op field")
         op = h["op"][0]
