@@ -6,13 +6,14 @@
 //                 pcl::KdTreeFLANN::setInputCloud (:567-568): LDS counting-sort of each "last" cloud into two spatial
 //                 hash grids (3-D cells on two levels, (x, y, ring) cells) + the flag that says whether the cloud is ring-sorted, which is what turns
 //                 the reference's walk-until-break loops into "ring key within +-2" tests
-//   k_associate   TransformToStart (:111-129) + nearestKSearch(k=1) (:302,390) + the ring-adjacent second / third
-//                 neighbour walks (:304-384, :392-482), one wave per query: exact 1-NN by expanding cubic shells of
-//                 hash cells with the f32 distance ((dx*dx+dy*dy)+dz*dz) FLANN's L2_Simple accumulates (lowest index
-//                 wins exact ties); the walk candidates come first from the 1-NN block's own candidates, then from the
-//                 (x, y, ring) grid; clouds that are not ring-sorted fall back to the literal loops inside the same
-//                 kernel.  With aloam_config.distortion the per-point interpolation ratio of DISTORTION 1 is applied
-//                 (:115-116, :376-377, :474-475; separate template instantiations)
+//   k_associate_pair (round 4; k_associate = the one-query-per-wave form of rounds 1-3, kept for A/B builds and, as k_associate_flagged, for clouds that
+//                 are not ring-sorted)
+//                 nearestKSearch(k=1) (:302,390) + the ring-adjacent second / third neighbour walks (:304-384, :392-482) on the features
+//                 k_transform_queries moved to the sweep start (:111-129), TWO queries per wave: exact 1-NN over the 3x3x3 block of fine hash
+//                 cells with the f32 distance ((dx*dx+dy*dy)+dz*dz) FLANN's L2_Simple accumulates (lowest index wins exact ties), the walk
+//                 candidates from the keys that block left in registers; coarse shells / the (x, y, ring) grid as tails for the queries whose
+//                 neighbours lie beyond the block.  The association does not depend on aloam_config.distortion (the features arrive
+//                 de-skewed from k_transform_queries; the interpolation ratio travels in the record for k_solve)
 //   k_solve       ceres::Problem + ceres::Solve (:284-291,380-381,478-479,494-499): per-correspondence
 //                 LidarEdgeFactor / LidarPlaneFactor residual + closed-form Jacobian (reference src/lidarFactor.hpp:
 //                 18-43,68-90), Huber(0.1) re-weighting, reduction to the 6x6 J^T J / J^T r / cost with wave64
