@@ -265,6 +265,7 @@ def roofline_of(prof, steps, B, sensor, mapping):
                 r["valu"] = valu
                 if dname in valu:
                     r["bound"] = "valu"     # the dominant kernel is instruction-bound: `achieved` / `frac` stay its HBM view, r["valu"][kernel] is its ceiling
+                    r["binding_ceiling"] = f"roofline.valu[{dname}]: {valu[dname]['achieved']} of {VALU_PEAK_GINST} G wave-instructions/s = {valu[dname]['frac']}; achieved / peak / frac above are its algorithmic bytes against HBM"
             break
     return r
 
