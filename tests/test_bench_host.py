@@ -62,3 +62,31 @@ def test_self_spawn_really_starts_the_ranks():
     assert all(d["WORLD_SIZE"] == "3" and d["MASTER_ADDR"] == "127.0.0.1" and d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" for d in ranks)
     assert len({d["MASTER_PORT"] for d in ranks}) == 1 and int(ranks[0]["MASTER_PORT"]) > 0
     assert all(d["argv"] == ["--gpus", "3", "--batch", "7", "--steps", "2"] for d in ranks)      # every rank gets the caller's flags
+
+
+def test_roofline_objects_attach_only_counters_of_this_library(tmp_path, monkeypatch):
+    """bench.py's roofline object: dominant kernel by hipEvent time, HBM view from the algorithmic bytes, `traffic` and the instruction-side
+    `valu` objects from the counter set under profiles/ — but only when that set carries the sha256 of the library the bench is running."""
+    b = _bench()
+    prof = {"k_ring_features": {"total_ms": 24.0, "launches": 10, "bytes_per_launch": 2.4e9},
+            "k_associate[plane]": {"total_ms": 22.0, "launches": 20, "bytes_per_launch": 0.74e9},
+            "k_scatter": {"total_ms": 8.0, "launches": 10, "bytes_per_launch": 4.0e9}}
+    pm = {"batch": 1024, "mapping": False, "sensor": "HDL-64", "lib_sha256": "abc", "source": "test",
+          "fetch_kib": {"k_ring_features<2048>": 1.0e6, "k_associate_pair<true, false>": 9.0e5}, "write_kib": {"k_ring_features<2048>": 5.0e5, "k_associate_pair<true, false>": 4.0e4},
+          "sq": {"k_ring_features<2048>": {"SQ_INSTS_VALU": 1.0e9, "SQ_ACTIVE_INST_VALU": 1.0e9, "avg_us": 2400.0},
+                 "k_associate_pair<true, false>": {"SQ_INSTS_VALU": 4.6e8, "SQ_ACTIVE_INST_VALU": 4.6e8, "avg_us": 1000.0}}}
+    root = tmp_path / "repo"
+    (root / "profiles").mkdir(parents=True)
+    json.dump(pm, open(root / "profiles" / "pmc_traffic_latest.json", "w"))
+    monkeypatch.setattr(b, "ROOT", str(root))
+    monkeypatch.setattr(b, "lib_sha256", lambda: "abc")
+    r = b.roofline_of(prof, 10, 1024, "HDL-64", False)
+    assert r["kernel"] == "k_ring_features" and abs(r["achieved"] - 1000.0) < 1e-6 and abs(r["frac"] - 0.125) < 1e-6
+    assert r["traffic"] == round((2 * 1.0e6 + 5.0e5) * 1024)
+    v = r["valu"]["k_ring_features"]
+    assert r["bound"] == "valu" and v["bound"] == "valu" and abs(v["achieved"] - 1.0e9 / 2.4e-3 / 1e9) < 0.1 and abs(v["peak"] - 614.4) < 1e-9
+    assert abs(v["busy"] - 1.0e9 * 4 / (1024 * 2.4e-3 * 2.4e9)) < 1e-3 and "binding_ceiling" in r
+    assert abs(r["valu"]["k_associate[plane]"]["valu_instructions_per_launch"] - 4.6e8) < 1
+    monkeypatch.setattr(b, "lib_sha256", lambda: "another build")
+    r = b.roofline_of(prof, 10, 1024, "HDL-64", False)
+    assert r["traffic"] is None and "valu" not in r and r["bound"] == "hbm" and "not attached" in r["traffic_note"]
