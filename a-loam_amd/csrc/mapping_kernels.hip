@@ -33,6 +33,24 @@ __device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i :
 __device__ __forceinline__ unsigned hash_cell(int a, int b, int c) {
   return ((unsigned)a * 73856093u) ^ ((unsigned)b * 19349663u) ^ ((unsigned)c * 83492791u);
 }
+// Bucket of a 2 m map cell: the low kMapLocalBits bits of each cell coordinate, interleaved (x, y, z, x, y, z, ...), are the low bits of
+// the bucket, the hash of the super-cell of 2^kMapLocalBits cells per axis the rest.  Neighbouring cells differ in a parity, so the
+// eight cells of any 2x2x2 block land in eight DIFFERENT buckets (k_map_search walks them without a duplicate test), and the cells of
+// one super-cell are neighbours in the bucket table and therefore in the sorted copy of the submap: the 64 queries of a wave, close
+// together in space, read close together in memory.
+#ifndef ALOAM_MAP_BUCKET_BITS
+#define ALOAM_MAP_BUCKET_BITS 1
+#endif
+constexpr int kMapLocalBits = ALOAM_MAP_BUCKET_BITS;
+__device__ __forceinline__ unsigned map_local_bits(int v, int axis) {      // bit i of v -> bit 3 i + axis
+  unsigned l = 0;
+#pragma unroll
+  for (int i = 0; i < kMapLocalBits; ++i) l |= (unsigned)((v >> i) & 1) << (3 * i + axis);
+  return l;
+}
+__device__ __forceinline__ unsigned map_bucket(int x, int y, int z, int H) {
+  return ((hash_cell(x >> kMapLocalBits, y >> kMapLocalBits, z >> kMapLocalBits) << (3 * kMapLocalBits)) | map_local_bits(x, 0) | map_local_bits(y, 1) | map_local_bits(z, 2)) & (unsigned)(H - 1);
+}
 
 // Hamilton product a * b (x,y,z,w storage), as Eigen evaluates it.
 __device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4]) {
@@ -928,7 +946,7 @@ __global__ __launch_bounds__(256) void k_mapgrid_count(MapArgs a) {
   int* cnt = a.grid_cnt[cls] + (long long)b * H;
   for (int g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
     const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
-    atomicAdd(&cnt[hash_cell((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv)) & (H - 1)], 1);
+    atomicAdd(&cnt[map_bucket((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv), H)], 1);
   }
 }
 
@@ -964,7 +982,7 @@ __global__ __launch_bounds__(256) void k_mapgrid_fill(MapArgs a) {
   float4* sorted = a.grid_sorted[cls] + (long long)b * a.pool_cap;
   for (int g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
     const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
-    const int pos = atomicAdd(&cur[hash_cell((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv)) & (H - 1)], 1);
+    const int pos = atomicAdd(&cur[map_bucket((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv), H)], 1);
     sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(g));
   }
 }
@@ -1000,7 +1018,7 @@ __global__ __launch_bounds__(1024) void k_mapgrid_build(MapArgs a) {
       p[u] = pool[s_off[lo] + (g - s_pref[lo])];
     }
   };
-  auto bucket = [&](const float4& p) { return (int)(hash_cell((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv)) & (unsigned)(H - 1)); };
+  auto bucket = [&](const float4& p) { return (int)map_bucket((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv), H); };
   for (int base = 0; base < n; base += U * 1024) {
     float4 p[U];
     fetch(base, p);
@@ -1182,6 +1200,13 @@ __device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[
 
 }  // namespace
 
+#ifndef ALOAM_MAP_SEARCH_V2
+#define ALOAM_MAP_SEARCH_V2 0     // A/B builds: 1 = candidate lists + reuse by the second LM iteration (round 5: measured slower, 6.15 against 4.94 ms)
+#endif
+#ifndef ALOAM_MAP_SEARCH_THREADS
+#define ALOAM_MAP_SEARCH_THREADS 256
+#endif
+constexpr int kMapSearchThreads = ALOAM_MAP_SEARCH_THREADS;
 #ifndef ALOAM_MAP_SEARCH_U
 #define ALOAM_MAP_SEARCH_U 4      // A/B builds: loads in flight per lane (measured, map_associate per step: 2: 7.76 ms, 4: 6.91, 6: 7.09, 8: 7.01)
 #endif
@@ -1196,8 +1221,10 @@ __device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[
 #endif
 // Search half: lane per query, few registers, so that many waves hide the latency of the bucket walks.  Writes the five
 // neighbours (x, y, z each; ascending (distance, index)) or a "not found" mark to a.knn[query].
+#if !ALOAM_MAP_SEARCH_V2
 template <int CLS>
-__global__ __launch_bounds__(256) void k_map_search(MapArgs a, int nblk) {
+__global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int nblk, int first) {
+  (void)first;
   // XCD-aware work mapping (as in k_associate): workgroups are dealt round-robin over the 8 XCDs by linear id, and every XCD has its
   // own L2.  The bucketed submap of a sequence (~0.7 MB) is read by all of that sequence's workgroups, so the 1-D grid is decoded
   // such that XCD x works through sequences x, x + 8, ...: one L2 fetches a sequence's submap instead of eight.
@@ -1231,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_map_search(MapArgs a, int nblk) {
     unsigned hh[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {                                            // the 8 bucket heads first: independent loads
-      hh[c] = hash_cell((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz) & (unsigned)(H - 1);
+      hh[c] = map_bucket((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz, H);
       s0[c] = start[hh[c]]; s1[c] = start[hh[c] + 1];
     }
     // Two of the eight cells may share a bucket: it is walked once.  Other cells hashed into a bucket need no test of their own:
@@ -1246,12 +1273,20 @@ __global__ __launch_bounds__(256) void k_map_search(MapArgs a, int nblk) {
     auto visit = [&](const float4& p) {
       const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
       const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;                   // FLANN L2_Simple, f32
+#if defined(ALOAM_MAP_DEBUG_NOINSERT)   // timing experiment only (wrong results): the walk without the sorted five
+      if (d < top.d[0]) { top.d[0] = d; top.x[0] = p.x; top.y[0] = p.y; top.z[0] = p.z; }
+#else
       if (d < 1.0f) top.insert(d, __float_as_int(p.w), p.x, p.y, p.z);
+#endif
     };
     constexpr int U = ALOAM_MAP_SEARCH_U;                                    // independent loads in flight per lane
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
+#if defined(ALOAM_MAP_DEBUG_HALF)       // timing experiment only (wrong results): every other group of U candidates skipped
+      for (int k = s0[c]; k < s1[c]; k += 2 * U) {
+#else
       for (int k = s0[c]; k < s1[c]; k += U) {
+#endif
         const int m = s1[c] - k;
         float4 p[U];
 #pragma unroll
@@ -1268,6 +1303,220 @@ __global__ __launch_bounds__(256) void k_map_search(MapArgs a, int nblk) {
     out[3] = make_float4(top.z[3], top.x[4], top.y[4], top.z[4]);
   }
 }
+#endif  // !ALOAM_MAP_SEARCH_V2
+
+#ifdef ALOAM_MAP_STATS   // debug builds: what the submap search does, summed over a run (tools/ab_check.py prints it)
+__device__ unsigned long long g_map_stats[2][8];   // [class]: 0 queries walked in iteration 0, 1 their list entries, 2 overflows, 3 queries of later iterations, 4 walked again, 5 entries drained there
+#define MAP_STAT(i, v) atomicAdd(&g_map_stats[CLS][i], (unsigned long long)(v))
+#else
+#define MAP_STAT(i, v) do {} while (0)
+#endif
+#if ALOAM_MAP_SEARCH_V2
+// Round 5.  Lane per query as before, but the walk over the 2x2x2 block no longer maintains the sorted five: with 64 queries in
+// lock-step SOME lane accepts a candidate at almost every step, so the whole wave paid the insertion (~60 instructions under
+// exec masks) per step.  Now
+//  * the walk only APPENDS the position of every candidate closer than kMapListR2 (1.1 m, squared) to the query's candidate
+//    list (global memory, one row of 64 lanes per list slot: coalesced), and a second loop DRAINS the list — a dozen entries
+//    instead of 30 - 200 candidates — into five packed 64-bit keys (distance bits << 32 | submap index << 5 | list slot) by a
+//    branch-free insertion: order (distance, index) exactly as before; the neighbours' coordinates are fetched through the slot
+//    at the end;
+//  * the lists outlive the kernel.  The second LM iteration of a frame (`first` == 0) moves every query by the pose correction of
+//    the first solve only.  A query that (a) moved less than kMapReuseShift (0.099 m) from where its list was made and (b) still
+//    has the same 2x2x2 block (same cell, same sides) finds every point closer than 1 m in that list: such a point lies in the
+//    block (the block covers 1 m around a query, below) and is closer than 1.099 m to the old position (triangle inequality; the
+//    1 mm of slack to 1.1 m is orders above f32 rounding at map coordinates).  Those queries only drain.  The others are
+//    collected in an LDS work list and walked afterwards by densely filled waves, so a wave does not pay a walk for one lane;
+//  * a list that overflows its K rows sends its query through the direct form (walk + insertion at once), exact too.
+// reference: src/laserMapping.cpp:580-582,646-650 (nearestKSearch(pointSel, 5, ...) and the `pointSearchSqDis[4] < 1.0` gate).
+constexpr float kMapListR2 = 1.21f;                         // (1 + 0.1)^2
+constexpr float kMapReuseShift2 = 0.099f * 0.099f;
+struct __attribute__((packed, aligned(4))) MapIntPair { int a, b; };
+typedef float mfloat2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dist_to_map(const float4& p, mfloat2 sxy, float sz) {
+  const mfloat2 pxy = {p.x, p.y};
+  const mfloat2 dxy = pxy - sxy, qxy = dxy * dxy;                             // packed f32: the same two subtractions and products
+  const float ddz = p.z - sz;
+  return (qxy.x + qxy.y) + ddz * ddz;                                         // FLANN L2_Simple, f32: (dx^2 + dy^2) + dz^2
+}
+struct Keys5 {
+  unsigned long long t[5];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) t[k] = 0x3f800000ull << 32;                   // (1.0f, 0): a key is below it exactly when its distance is < 1.0f
+  }
+  __device__ __forceinline__ void insert(unsigned long long k) {              // t stays ascending; branch-free
+    const bool c0 = k < t[0], c1 = k < t[1], c2 = k < t[2], c3 = k < t[3], c4 = k < t[4];
+    t[4] = c3 ? t[3] : (c4 ? k : t[4]);
+    t[3] = c2 ? t[2] : (c3 ? k : t[3]);
+    t[2] = c1 ? t[1] : (c2 ? k : t[2]);
+    t[1] = c0 ? t[0] : (c1 ? k : t[1]);
+    t[0] = c0 ? k : t[0];
+  }
+};
+// own cell and the side of the block per axis, packed for the "same block" test: three 10-bit-free ints would do, a struct is clearer
+struct MapBlock { int cx, cy, cz, nx, ny, nz; };
+__device__ __forceinline__ MapBlock map_block(float x, float y, float z) {
+  const float gx = x * kMapCellInv, gy = y * kMapCellInv, gz = z * kMapCellInv;
+  MapBlock k;
+  k.cx = (int)floorf(gx); k.cy = (int)floorf(gy); k.cz = (int)floorf(gz);
+  k.nx = gx - (float)k.cx >= 0.5f ? k.cx + 1 : k.cx - 1; k.ny = gy - (float)k.cy >= 0.5f ? k.cy + 1 : k.cy - 1; k.nz = gz - (float)k.cz >= 0.5f ? k.cz + 1 : k.cz - 1;
+  return k;
+}
+template <int CLS>
+__global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int nblk, int first) {
+  constexpr int K = CLS == 0 ? kMapListK0 : kMapListK1;
+  constexpr int NT = kMapSearchThreads;
+#if ALOAM_MAP_SEARCH_XCD
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int b = (slot / nblk) * 8 + xcd, blk = slot % nblk;
+  if (b >= a.B) return;
+#else
+  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
+#endif
+  const MapSeq& ms = a.seq[b];
+  const int n = ms.n_stack[CLS];
+  const long long per = CLS == 0 ? a.R * 120 : a.cap;
+  const long long sb = (long long)b * per;
+  if (!ms.gate) return;
+  double par[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
+  const int H = a.grid_H[CLS];
+  const int* __restrict__ start = a.grid_start[CLS] + (long long)b * (H + 1);
+  const float4* __restrict__ sorted = a.grid_sorted[CLS] + (long long)b * a.pool_cap;
+  // Everything below is addressed as (wave-uniform per-sequence base) + (32-bit byte offset): one VGPR per address, no 64-bit lane math.
+  const char* __restrict__ sorted_b = reinterpret_cast<const char*>(sorted);
+  char* __restrict__ cand_b = reinterpret_cast<char*>(a.cand[CLS] + (long long)b * ((per + 63) >> 6) * ((K + 1) * 64));
+  char* __restrict__ qinfo_b = reinterpret_cast<char*>(a.qinfo[CLS] + sb);
+  char* __restrict__ knn_b = reinterpret_cast<char*>(a.knn + (long long)b * a.cap * 4);
+  const char* __restrict__ start_b = reinterpret_cast<const char*>(start);
+  __shared__ int s_work[NT];
+  __shared__ int s_nwork;
+  auto point_at = [&](unsigned pos) -> float4 { return *reinterpret_cast<const float4*>(sorted_b + (pos << 4)); };
+  auto entry = [&](unsigned ofs) -> int& { return *reinterpret_cast<int*>(cand_b + ofs); };
+  // list row j of query i: int [(i >> 6) * (K + 1) * 64 + j * 64 + (i & 63)] of the sequence's lists; row K takes what overflows
+  auto list_of = [&](int i) { return (unsigned)(((i >> 6) * ((K + 1) * 64) + (i & 63)) << 2); };
+  auto store_knn = [&](int i, bool found, const float4* q) {
+    float4* out = reinterpret_cast<float4*>(knn_b + ((unsigned)i << 6));
+    if (found) {
+      out[0] = make_float4(q[0].x, q[0].y, q[0].z, 1.f);
+      out[1] = make_float4(q[1].x, q[1].y, q[1].z, q[2].x);
+      out[2] = make_float4(q[2].y, q[2].z, q[3].x, q[3].y);
+      out[3] = make_float4(q[3].z, q[4].x, q[4].y, q[4].z);
+    } else {
+      out[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+
+  // the five neighbours out of the list (cnt <= K) -> knn
+  auto drain = [&](int i, const float4& sel, unsigned lst, int cnt) {
+    const mfloat2 sxy = {sel.x, sel.y};
+    Keys5 top;
+    top.init();
+    for (int j = 0; j < cnt; j += 2) {                                        // two entries in flight
+      const bool two = j + 1 < cnt;
+      const int p0 = entry(lst + (j << 8)), p1 = entry(lst + ((two ? j + 1 : j) << 8));
+      const float4 c0 = point_at(p0), c1 = point_at(p1);
+      const float d0 = dist_to_map(c0, sxy, sel.z), d1 = dist_to_map(c1, sxy, sel.z);
+      top.insert((unsigned long long)__float_as_uint(d0) << 32 | (unsigned)(__float_as_int(c0.w) << 5 | j));
+      top.insert((unsigned long long)(two ? __float_as_uint(d1) : 0x7f800000u) << 32 | (unsigned)(__float_as_int(c1.w) << 5 | (j + 1)));
+    }
+    const bool found = (unsigned)(top.t[4] >> 32) < 0x3f800000u;              // pointSearchSqDis[4] < 1.0
+    float4 q[5];
+    if (found) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) q[k] = point_at(entry(lst + (((unsigned)top.t[k] & 31u) << 8)));
+    }
+    store_knn(i, found, q);
+  };
+
+  // walk the block of query i: make its list, then drain it (or, on overflow, walk again in the direct form)
+  auto full = [&](int i, const float4& sel) {
+    const mfloat2 sxy = {sel.x, sel.y};
+    const MapBlock k = map_block(sel.x, sel.y, sel.z);
+    // hash terms and local bits of the two cells per axis, then the eight combinations (map_bucket(), spelled out)
+    const unsigned hx0 = (unsigned)(k.cx >> kMapLocalBits) * 73856093u, hx1 = (unsigned)(k.nx >> kMapLocalBits) * 73856093u;
+    const unsigned hy0 = (unsigned)(k.cy >> kMapLocalBits) * 19349663u, hy1 = (unsigned)(k.ny >> kMapLocalBits) * 19349663u;
+    const unsigned hz0 = (unsigned)(k.cz >> kMapLocalBits) * 83492791u, hz1 = (unsigned)(k.nz >> kMapLocalBits) * 83492791u;
+    const unsigned px0 = map_local_bits(k.cx, 0), px1 = map_local_bits(k.nx, 0), py0 = map_local_bits(k.cy, 1), py1 = map_local_bits(k.ny, 1), pz0 = map_local_bits(k.cz, 2), pz1 = map_local_bits(k.nz, 2);
+    int s0[8], s1[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {                                            // the 8 bucket heads first: independent 8-byte loads
+      const unsigned h = ((((c & 1) ? hx1 : hx0) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) << (3 * kMapLocalBits) | (((c & 1) ? px1 : px0) | ((c & 2) ? py1 : py0) | ((c & 4) ? pz1 : pz0))) & (unsigned)(H - 1);
+      const MapIntPair v = *reinterpret_cast<const MapIntPair*>(start_b + (h << 2));
+      s0[c] = v.a; s1[c] = v.b;
+    }
+    // The eight cells sit in eight different buckets (map_bucket).  Points of OTHER cells hashed into one of them need no test of their
+    // own: they are real map points, and a list (or the direct form) holding more real points than needed changes nothing — the drain
+    // keeps d < 1 only, and every point with d < 1 is in the block.
+    const unsigned lst = list_of(i);
+    constexpr int U = ALOAM_MAP_SEARCH_U;                                    // independent loads in flight per lane
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      for (int kk = s0[c]; kk < s1[c]; kk += U) {
+        const int m = s1[c] - kk;
+        float4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = point_at(u < m ? kk + u : kk);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float d = dist_to_map(p[u], sxy, sel.z);
+          if (u < m && d < kMapListR2) { entry(lst + ((cnt < K ? cnt : K) << 8)) = kk + u; ++cnt; }
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(qinfo_b + ((unsigned)i << 4)) = make_float4(sel.x, sel.y, sel.z, __int_as_float(cnt));
+    if (first) { MAP_STAT(0, 1); MAP_STAT(1, cnt); if (cnt > K) MAP_STAT(2, 1); } else MAP_STAT(4, 1);
+    if (cnt <= K) { drain(i, sel, lst, cnt); return; }
+    // direct form (a query with more than K map points inside 1.1 m): every candidate inserted at once, neighbours by submap index
+    Keys5 top;
+    top.init();
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      for (int kk = s0[c]; kk < s1[c]; ++kk) {
+        const float4 p = point_at(kk);
+        top.insert((unsigned long long)__float_as_uint(dist_to_map(p, sxy, sel.z)) << 32 | (unsigned)(__float_as_int(p.w) << 5));
+      }
+    const bool found = (unsigned)(top.t[4] >> 32) < 0x3f800000u;
+    float4 q[5];
+    if (found) {
+      const int* tab = a.tab + (long long)b * kTabInts;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) q[j] = submap_point(a, b, CLS, tab, ms.n_valid, (int)((unsigned)top.t[j] >> 5));
+    }
+    store_knn(i, found, q);
+  };
+
+  for (int base = blk * NT; base < n; base += nblk * NT) {                   // grid-stride over the stack, uniform per workgroup
+    const int i = base + (int)threadIdx.x;
+    if (first) {
+      if (i < n) full(i, associate_to_map(a.stack[CLS][sb + i], par));       // pointSel (:580, :646)
+      continue;
+    }
+    if (threadIdx.x == 0) s_nwork = 0;
+    __syncthreads();
+    if (i < n) {
+      const float4 sel = associate_to_map(a.stack[CLS][sb + i], par);
+      const float4 q1 = *reinterpret_cast<const float4*>(qinfo_b + ((unsigned)i << 4));
+      const int cnt = __float_as_int(q1.w);
+      const float sx = sel.x - q1.x, sy = sel.y - q1.y, sz = sel.z - q1.z;
+      const MapBlock k1 = map_block(q1.x, q1.y, q1.z), k2 = map_block(sel.x, sel.y, sel.z);
+      const bool same = ((k1.cx ^ k2.cx) | (k1.cy ^ k2.cy) | (k1.cz ^ k2.cz) | (k1.nx ^ k2.nx) | (k1.ny ^ k2.ny) | (k1.nz ^ k2.nz)) == 0;
+      MAP_STAT(3, 1);
+      if (same && (sx * sx + sy * sy) + sz * sz < kMapReuseShift2 && cnt <= K) { MAP_STAT(5, cnt); drain(i, sel, list_of(i), cnt); }
+      else s_work[atomicAdd(&s_nwork, 1)] = i;
+    }
+    __syncthreads();
+    const int nw = s_nwork;
+    for (int w = threadIdx.x; w < nw; w += NT) {
+      const int j = s_work[w];
+      full(j, associate_to_map(a.stack[CLS][sb + j], par));
+    }
+    __syncthreads();
+  }
+}
+#endif  // ALOAM_MAP_SEARCH_V2
 
 // Fit half: line fit (corner) / plane fit (surf) in f64 on the five neighbours, validity tests, factor record.
 template <int CLS>
@@ -1698,11 +1947,14 @@ void launch_map_grid(const MapArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(k_mapgrid_fill, g, dim3(256), 0, s, a);
 }
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
-  (void)iter;
   const int by = (a.B + 7) / 8 * 8;                      // padded so that every (XCD, sequence slot) pair exists
-  hipLaunchKernelGGL(k_map_search<0>, dim3(ALOAM_MAP_SEARCH_NBLK0 * by), dim3(256), 0, s, a, ALOAM_MAP_SEARCH_NBLK0);
+  const int first = iter == 0 ? 1 : 0;                   // the lists of iteration 0 serve the later ones (k_map_search)
+#ifndef ALOAM_MAP_DEBUG_LDS
+#define ALOAM_MAP_DEBUG_LDS 0      // occupancy experiments: dynamic LDS bytes per search workgroup (nothing uses them)
+#endif
+  hipLaunchKernelGGL(k_map_search<0>, dim3(ALOAM_MAP_SEARCH_NBLK0 * by), dim3(kMapSearchThreads), ALOAM_MAP_DEBUG_LDS, s, a, ALOAM_MAP_SEARCH_NBLK0, first);
   hipLaunchKernelGGL(k_map_fit<0>, dim3(16, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_map_search<1>, dim3(ALOAM_MAP_SEARCH_NBLK1 * by), dim3(256), 0, s, a, ALOAM_MAP_SEARCH_NBLK1);
+  hipLaunchKernelGGL(k_map_search<1>, dim3(ALOAM_MAP_SEARCH_NBLK1 * by), dim3(kMapSearchThreads), ALOAM_MAP_DEBUG_LDS, s, a, ALOAM_MAP_SEARCH_NBLK1, first);
   hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) {
@@ -1719,3 +1971,6 @@ void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s) {
 void launch_map_register(const MapArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_map_register, dim3((a.cap + 255) / 256, a.B), dim3(256), 0, s, a); }
 
 }  // namespace aloam
+#ifdef ALOAM_MAP_STATS
+extern "C" int aloam_debug_map_stats(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(aloam::g_map_stats), sizeof(unsigned long long) * 16); }
+#endif
