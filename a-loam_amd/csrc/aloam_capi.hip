@@ -78,7 +78,6 @@ struct aloam_ctx {
   int *d_addcnt = nullptr, *d_cursor = nullptr, *d_compact_flag = nullptr;
   float4* d_mgrid_sorted[2] = {nullptr, nullptr}; int* d_mgrid_start[2] = {nullptr, nullptr}; int* d_mgrid_cnt[2] = {nullptr, nullptr};
   MapEdgeRec* d_medges = nullptr; MapNormRec* d_mnorms = nullptr; float4* d_registered = nullptr; float4* d_knn = nullptr;
-  int* d_mcand[2] = {nullptr, nullptr}; float4* d_mqinfo[2] = {nullptr, nullptr};   // candidate lists of the submap search (k_map_search)
   int* d_vox_lists = nullptr;
   int* d_rec_tiles = nullptr; int rec_tiles_corner = 0, rec_tiles_per_seq = 0;
   VoxSeg* d_segs = nullptr; int *d_tile_seg = nullptr, *d_tile_heads = nullptr, *d_tile_pref = nullptr, *d_vox_counters = nullptr, *d_bbox = nullptr;
@@ -367,8 +366,7 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
                   c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
-                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag, c->d_vox_lists, c->d_rec_tiles,
-                  c->d_mcand[0], c->d_mcand[1], c->d_mqinfo[0], c->d_mqinfo[1]};
+                  c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag, c->d_vox_lists, c->d_rec_tiles};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_nin) (void)hipHostFree(c->h_nin);
@@ -855,7 +853,6 @@ static MapArgs map_args(aloam_ctx* c) {
   for (int k = 0; k < 2; ++k) {
     a.pool[k] = c->d_pool[k]; a.stack[k] = c->d_stack[k]; a.stack_world[k] = c->d_stack_world[k]; a.stack_cube[k] = c->d_stack_cube[k];
     a.grid_sorted[k] = c->d_mgrid_sorted[k]; a.grid_start[k] = c->d_mgrid_start[k]; a.grid_cnt[k] = c->d_mgrid_cnt[k]; a.grid_H[k] = c->map_H[k];
-    a.cand[k] = c->d_mcand[k]; a.qinfo[k] = c->d_mqinfo[k];
   }
   a.addcnt = c->d_addcnt; a.cursor = c->d_cursor; a.compact_flag = c->d_compact_flag;
   a.edges = c->d_medges; a.norms = c->d_mnorms; a.knn = c->d_knn;
@@ -910,8 +907,6 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
     if ((rc = dmalloc(c, &c->d_mgrid_start[k], B * ((size_t)c->map_H[k] + 1)))) return rc;
     if ((rc = dmalloc(c, &c->d_mgrid_cnt[k], B * (size_t)c->map_H[k]))) return rc;
     if ((rc = dmalloc(c, &c->d_keys[k], (size_t)c->map_key_cap))) return rc;
-    if ((rc = dmalloc(c, &c->d_mcand[k], B * ((per + 63) / 64) * (size_t)(((k == 0 ? kMapListK0 : kMapListK1) + 1) * 64)))) return rc;
-    if ((rc = dmalloc(c, &c->d_mqinfo[k], B * per))) return rc;
   }
   c->rec_tiles_corner = (int)((R * 120 + 255) / 256);
   c->rec_tiles_per_seq = c->rec_tiles_corner + (int)((cap + 255) / 256);

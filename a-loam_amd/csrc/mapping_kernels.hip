@@ -1057,6 +1057,15 @@ __global__ __launch_bounds__(1024) void k_mapgrid_build(MapArgs a) {
 // =======================================================================================================
 namespace {
 
+struct __attribute__((packed, aligned(4))) MapIntPair { int a, b; };      // start[h], start[h + 1] by one 8-byte load
+typedef float mfloat2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dist_to_map(const float4& p, mfloat2 sxy, float sz) {
+  const mfloat2 pxy = {p.x, p.y};
+  const mfloat2 dxy = pxy - sxy, qxy = dxy * dxy;                             // packed f32: the same two subtractions and products
+  const float ddz = p.z - sz;
+  return (qxy.x + qxy.y) + ddz * ddz;                                         // FLANN L2_Simple, f32: (dx^2 + dy^2) + dz^2
+}
+
 struct Top5 {
   float d[5]; int id[5]; float x[5], y[5], z[5];
   __device__ __forceinline__ void init() {
@@ -1078,6 +1087,26 @@ struct Top5 {
         tf = z[s]; z[s] = z[s - 1]; z[s - 1] = tf;
       }
     }
+  }
+};
+
+// The same five as packed keys (f32 distance bits << 32 | submap index: one 64-bit compare orders by (distance, index), the order
+// Top5 keeps) + the position of the entry in the bucketed copy; coordinates are fetched through the position at the end: 15 registers
+// instead of 25, which is what takes k_map_search from 72 - 74 to <= 64 registers (eight waves per SIMD).
+struct Top5P {
+  unsigned long long k[5]; int pos[5];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int s = 0; s < 5; ++s) { k[s] = 0x3f800000ull << 32; pos[s] = 0; }    // (1.0f, 0): a key is below it exactly when its distance is < 1.0f
+  }
+  __device__ __forceinline__ void insert(float dd, int ii, int pp) {          // branch-free; k stays ascending
+    const unsigned long long key = (unsigned long long)__float_as_uint(dd) << 32 | (unsigned)ii;
+    const bool c0 = key < k[0], c1 = key < k[1], c2 = key < k[2], c3 = key < k[3], c4 = key < k[4];
+    k[4] = c3 ? k[3] : (c4 ? key : k[4]); pos[4] = c3 ? pos[3] : (c4 ? pp : pos[4]);
+    k[3] = c2 ? k[2] : (c3 ? key : k[3]); pos[3] = c2 ? pos[2] : (c3 ? pp : pos[3]);
+    k[2] = c1 ? k[1] : (c2 ? key : k[2]); pos[2] = c1 ? pos[1] : (c2 ? pp : pos[2]);
+    k[1] = c0 ? k[0] : (c1 ? key : k[1]); pos[1] = c0 ? pos[0] : (c1 ? pp : pos[1]);
+    k[0] = c0 ? key : k[0];               pos[0] = c0 ? pp : pos[0];
   }
 };
 
@@ -1200,8 +1229,14 @@ __device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[
 
 }  // namespace
 
-#ifndef ALOAM_MAP_SEARCH_V2
-#define ALOAM_MAP_SEARCH_V2 0     // A/B builds: 1 = candidate lists + reuse by the second LM iteration (round 5: measured slower, 6.15 against 4.94 ms)
+#ifndef ALOAM_MAP_SEARCH_COOP
+#define ALOAM_MAP_SEARCH_COOP 0   // A/B builds: 1 = G lanes per query with LDS lists (round 5: measured slower, 5.72 against 4.65 ms)
+#endif
+#ifndef ALOAM_MAP_COOP_G0
+#define ALOAM_MAP_COOP_G0 8       // lanes per corner query
+#endif
+#ifndef ALOAM_MAP_COOP_G1
+#define ALOAM_MAP_COOP_G1 4       // lanes per surf query
 #endif
 #ifndef ALOAM_MAP_SEARCH_THREADS
 #define ALOAM_MAP_SEARCH_THREADS 256
@@ -1209,6 +1244,12 @@ __device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[
 constexpr int kMapSearchThreads = ALOAM_MAP_SEARCH_THREADS;
 #ifndef ALOAM_MAP_SEARCH_U
 #define ALOAM_MAP_SEARCH_U 4      // A/B builds: loads in flight per lane (measured, map_associate per step: 2: 7.76 ms, 4: 6.91, 6: 7.09, 8: 7.01)
+#endif
+#ifndef ALOAM_MAP_TOP5_PACKED
+#define ALOAM_MAP_TOP5_PACKED 1    // A/B builds: 0 = the five neighbours with their coordinates in registers (rounds 2 - 4)
+#endif
+#ifndef ALOAM_MAP_SEARCH_TAILS
+#define ALOAM_MAP_SEARCH_TAILS 0   // A/B builds: 1 = full groups of U, then the rest under exec masks (round 5: 84 - 92 registers instead of 50, 5.00 against 4.70 ms)
 #endif
 #ifndef ALOAM_MAP_SEARCH_NBLK0
 #define ALOAM_MAP_SEARCH_NBLK0 16  // workgroups per sequence, corner / surf class (A/B builds)
@@ -1221,10 +1262,9 @@ constexpr int kMapSearchThreads = ALOAM_MAP_SEARCH_THREADS;
 #endif
 // Search half: lane per query, few registers, so that many waves hide the latency of the bucket walks.  Writes the five
 // neighbours (x, y, z each; ascending (distance, index)) or a "not found" mark to a.knn[query].
-#if !ALOAM_MAP_SEARCH_V2
+#if !ALOAM_MAP_SEARCH_COOP
 template <int CLS>
-__global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int nblk, int first) {
-  (void)first;
+__global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int nblk) {
   // XCD-aware work mapping (as in k_associate): workgroups are dealt round-robin over the 8 XCDs by linear id, and every XCD has its
   // own L2.  The bucketed submap of a sequence (~0.7 MB) is read by all of that sequence's workgroups, so the 1-D grid is decoded
   // such that XCD x works through sequences x, x + 8, ...: one L2 fetches a sequence's submap instead of eight.
@@ -1250,31 +1290,29 @@ __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int
     const float gx = sel.x * kMapCellInv, gy = sel.y * kMapCellInv, gz = sel.z * kMapCellInv;
     const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
     const int nx = gx - (float)cx >= 0.5f ? cx + 1 : cx - 1, ny = gy - (float)cy >= 0.5f ? cy + 1 : cy - 1, nz = gz - (float)cz >= 0.5f ? cz + 1 : cz - 1;
+#if ALOAM_MAP_TOP5_PACKED
+    Top5P top;
+#else
     Top5 top;
+#endif
     top.init();
     // the reference discards the 5-NN result unless the 5th neighbour is closer than 1 m (:582, :650): collecting every point
     // with d < 1 from the 2x2x2 block and keeping the five smallest (distance, index) is an exact stand-in
     int s0[8], s1[8];
-    unsigned hh[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {                                            // the 8 bucket heads first: independent loads
-      hh[c] = map_bucket((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz, H);
-      s0[c] = start[hh[c]]; s1[c] = start[hh[c] + 1];
+    for (int c = 0; c < 8; ++c) {                                            // the 8 bucket heads first: independent 8-byte loads
+      const unsigned h = map_bucket((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz, H);
+      const MapIntPair v = *reinterpret_cast<const MapIntPair*>(reinterpret_cast<const char*>(start) + (h << 2));
+      s0[c] = v.a; s1[c] = v.b;
     }
-    // Two of the eight cells may share a bucket: it is walked once.  Other cells hashed into a bucket need no test of their own:
-    // every point closer than 1 m lies in one of the eight cells, so a foreign point always fails d < 1.
-#pragma unroll
-    for (int c = 1; c < 8; ++c) {
-      bool dup = false;
-#pragma unroll
-      for (int e = 0; e < c; ++e) dup = dup || hh[e] == hh[c];
-      if (dup) s1[c] = s0[c];
-    }
-    auto visit = [&](const float4& p) {
+    // The eight cells sit in eight different buckets (map_bucket).  Other cells hashed into a bucket need no test of their own: every
+    // point closer than 1 m lies in one of the eight cells, so a foreign point always fails d < 1.
+    auto visit = [&](const float4& p, int at) {
       const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
       const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;                   // FLANN L2_Simple, f32
-#if defined(ALOAM_MAP_DEBUG_NOINSERT)   // timing experiment only (wrong results): the walk without the sorted five
-      if (d < top.d[0]) { top.d[0] = d; top.x[0] = p.x; top.y[0] = p.y; top.z[0] = p.z; }
+#if ALOAM_MAP_TOP5_PACKED
+      (void)at;
+      if (d < 1.0f) top.insert(d, __float_as_int(p.w), at);
 #else
       if (d < 1.0f) top.insert(d, __float_as_int(p.w), p.x, p.y, p.z);
 #endif
@@ -1282,90 +1320,90 @@ __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int
     constexpr int U = ALOAM_MAP_SEARCH_U;                                    // independent loads in flight per lane
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-#if defined(ALOAM_MAP_DEBUG_HALF)       // timing experiment only (wrong results): every other group of U candidates skipped
-      for (int k = s0[c]; k < s1[c]; k += 2 * U) {
+#if ALOAM_MAP_SEARCH_TAILS
+      // Full groups of U, then the rest under exec masks: a lane only loads what its bucket holds.  (The L1 looks one line up per
+      // lane and load whatever the lane does with it: re-reading entry k in the lanes past the end, as rounds 2 - 4 did, cost a
+      // third of the surf class's look-ups.)
+      int k = s0[c];
+      for (; k + U <= s1[c]; k += U) {
+        float4 p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) p[u] = sorted[k + u];
+#pragma unroll
+        for (int u = 0; u < U; ++u) visit(p[u], k + u);
+      }
+      {
+        const int m = s1[c] - k;                                               // 0 .. U - 1 left
+        float4 p[U - 1];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u) if (u < m) p[u] = sorted[k + u];
+#pragma unroll
+        for (int u = 0; u < U - 1; ++u) if (u < m) visit(p[u], k + u);
+      }
 #else
       for (int k = s0[c]; k < s1[c]; k += U) {
-#endif
         const int m = s1[c] - k;
         float4 p[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) p[u] = sorted[u < m ? k + u : k];
 #pragma unroll
-        for (int u = 0; u < U; ++u) if (u < m) visit(p[u]);
+        for (int u = 0; u < U; ++u) if (u < m) visit(p[u], k + u);
       }
+#endif
     }
     float4* out = a.knn + ((long long)b * a.cap + i) * 4;
+#if ALOAM_MAP_TOP5_PACKED
+    if ((unsigned)(top.k[4] >> 32) < 0x3f800000u) {                          // pointSearchSqDis[4] < 1.0
+      float4 q[5];
+#pragma unroll
+      for (int s = 0; s < 5; ++s) q[s] = sorted[top.pos[s]];
+      out[0] = make_float4(q[0].x, q[0].y, q[0].z, 1.f);
+      out[1] = make_float4(q[1].x, q[1].y, q[1].z, q[2].x);
+      out[2] = make_float4(q[2].y, q[2].z, q[3].x, q[3].y);
+      out[3] = make_float4(q[3].z, q[4].x, q[4].y, q[4].z);
+    } else {
+      out[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#else
     const bool found = top.d[4] < 1.0f;                                      // pointSearchSqDis[4] < 1.0
     out[0] = make_float4(top.x[0], top.y[0], top.z[0], found ? 1.f : 0.f);
     out[1] = make_float4(top.x[1], top.y[1], top.z[1], top.x[2]);
     out[2] = make_float4(top.y[2], top.z[2], top.x[3], top.y[3]);
     out[3] = make_float4(top.z[3], top.x[4], top.y[4], top.z[4]);
-  }
-}
-#endif  // !ALOAM_MAP_SEARCH_V2
-
-#ifdef ALOAM_MAP_STATS   // debug builds: what the submap search does, summed over a run (tools/ab_check.py prints it)
-__device__ unsigned long long g_map_stats[2][8];   // [class]: 0 queries walked in iteration 0, 1 their list entries, 2 overflows, 3 queries of later iterations, 4 walked again, 5 entries drained there
-#define MAP_STAT(i, v) atomicAdd(&g_map_stats[CLS][i], (unsigned long long)(v))
-#else
-#define MAP_STAT(i, v) do {} while (0)
 #endif
-#if ALOAM_MAP_SEARCH_V2
-// Round 5.  Lane per query as before, but the walk over the 2x2x2 block no longer maintains the sorted five: with 64 queries in
-// lock-step SOME lane accepts a candidate at almost every step, so the whole wave paid the insertion (~60 instructions under
-// exec masks) per step.  Now
-//  * the walk only APPENDS the position of every candidate closer than kMapListR2 (1.1 m, squared) to the query's candidate
-//    list (global memory, one row of 64 lanes per list slot: coalesced), and a second loop DRAINS the list — a dozen entries
-//    instead of 30 - 200 candidates — into five packed 64-bit keys (distance bits << 32 | submap index << 5 | list slot) by a
-//    branch-free insertion: order (distance, index) exactly as before; the neighbours' coordinates are fetched through the slot
-//    at the end;
-//  * the lists outlive the kernel.  The second LM iteration of a frame (`first` == 0) moves every query by the pose correction of
-//    the first solve only.  A query that (a) moved less than kMapReuseShift (0.099 m) from where its list was made and (b) still
-//    has the same 2x2x2 block (same cell, same sides) finds every point closer than 1 m in that list: such a point lies in the
-//    block (the block covers 1 m around a query, below) and is closer than 1.099 m to the old position (triangle inequality; the
-//    1 mm of slack to 1.1 m is orders above f32 rounding at map coordinates).  Those queries only drain.  The others are
-//    collected in an LDS work list and walked afterwards by densely filled waves, so a wave does not pay a walk for one lane;
-//  * a list that overflows its K rows sends its query through the direct form (walk + insertion at once), exact too.
-// reference: src/laserMapping.cpp:580-582,646-650 (nearestKSearch(pointSel, 5, ...) and the `pointSearchSqDis[4] < 1.0` gate).
-constexpr float kMapListR2 = 1.21f;                         // (1 + 0.1)^2
-constexpr float kMapReuseShift2 = 0.099f * 0.099f;
-struct __attribute__((packed, aligned(4))) MapIntPair { int a, b; };
-typedef float mfloat2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float dist_to_map(const float4& p, mfloat2 sxy, float sz) {
-  const mfloat2 pxy = {p.x, p.y};
-  const mfloat2 dxy = pxy - sxy, qxy = dxy * dxy;                             // packed f32: the same two subtractions and products
-  const float ddz = p.z - sz;
-  return (qxy.x + qxy.y) + ddz * ddz;                                         // FLANN L2_Simple, f32: (dx^2 + dy^2) + dz^2
+  }
 }
-struct Keys5 {
-  unsigned long long t[5];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) t[k] = 0x3f800000ull << 32;                   // (1.0f, 0): a key is below it exactly when its distance is < 1.0f
-  }
-  __device__ __forceinline__ void insert(unsigned long long k) {              // t stays ascending; branch-free
-    const bool c0 = k < t[0], c1 = k < t[1], c2 = k < t[2], c3 = k < t[3], c4 = k < t[4];
-    t[4] = c3 ? t[3] : (c4 ? k : t[4]);
-    t[3] = c2 ? t[2] : (c3 ? k : t[3]);
-    t[2] = c1 ? t[1] : (c2 ? k : t[2]);
-    t[1] = c0 ? t[0] : (c1 ? k : t[1]);
-    t[0] = c0 ? k : t[0];
-  }
+#endif  // !ALOAM_MAP_SEARCH_COOP
+
+#if ALOAM_MAP_SEARCH_COOP
+// Round 5: G lanes per query (8 corner / 4 surf) instead of one.  The lane-per-query kernel of rounds 2 - 4 is bound by the L1's tag
+// look-ups: every lane walks ITS buckets 16 bytes at a time, so each wave-wide load touches ~50 different 128-byte lines and costs the
+// L1 ~48 cycles (measured: time = loads x 48 cycles per CU for both classes; without the sorted-five insertion only -12 %, with half
+// the candidates -35 %).  Here the G lanes of a group read G CONSECUTIVE entries of a bucket — one line per group and load, 8 - 16 lines
+// per wave-wide load instead of ~50 —, and what is kept per candidate is cheap: a candidate closer than 1 m is appended to the group's
+// list in LDS (key = distance bits << 32 | submap index, coordinates beside it; position from the group's bits of the wave ballot),
+// and when the eight buckets are through, every list entry gets its RANK among the keys of its list by counting (keys are distinct:
+// the index is in them) — rank r < 5 is the r-th neighbour in (distance, index) order, exactly the order the lane-per-query kernel's
+// sorted five had.  A list that is about to outgrow its K rows is cut down to its five smallest the same way and the walk goes on:
+// exact for any number of neighbours.  A wave serves 64 consecutive stack points: one lane per point for pointAssociateToMap (f64),
+// then G passes of 64 / G points.   reference: src/laserMapping.cpp:580-582,646-650 (nearestKSearch(pointSel, 5, ...), `< 1.0` gate).
+template <int CLS> struct MapCoop {
+  static constexpr int G = CLS == 0 ? ALOAM_MAP_COOP_G0 : ALOAM_MAP_COOP_G1;   // lanes per query
+  static constexpr int NQ = 64 / G;                                            // queries per pass
+  static constexpr int K = 4 * G;                                              // list rows per query: four own entries per lane in the ranking
+  static constexpr int OWN = K / G;
+  struct Lds {                                                                 // per wave
+    float4 sel[64];
+    unsigned long long key[NQ][K];
+    float xyz[NQ][K][3];
+    int2 hd[NQ][8];
+    float out[NQ][16];
+  };
 };
-// own cell and the side of the block per axis, packed for the "same block" test: three 10-bit-free ints would do, a struct is clearer
-struct MapBlock { int cx, cy, cz, nx, ny, nz; };
-__device__ __forceinline__ MapBlock map_block(float x, float y, float z) {
-  const float gx = x * kMapCellInv, gy = y * kMapCellInv, gz = z * kMapCellInv;
-  MapBlock k;
-  k.cx = (int)floorf(gx); k.cy = (int)floorf(gy); k.cz = (int)floorf(gz);
-  k.nx = gx - (float)k.cx >= 0.5f ? k.cx + 1 : k.cx - 1; k.ny = gy - (float)k.cy >= 0.5f ? k.cy + 1 : k.cy - 1; k.nz = gz - (float)k.cz >= 0.5f ? k.cz + 1 : k.cz - 1;
-  return k;
-}
 template <int CLS>
-__global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int nblk, int first) {
-  constexpr int K = CLS == 0 ? kMapListK0 : kMapListK1;
-  constexpr int NT = kMapSearchThreads;
+__global__ __launch_bounds__(256) void k_map_search(MapArgs a, int nblk) {
+  using C = MapCoop<CLS>;
+  constexpr int G = C::G, NQ = C::NQ, K = C::K, OWN = C::OWN;
 #if ALOAM_MAP_SEARCH_XCD
   const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
   const int b = (slot / nblk) * 8 + xcd, blk = slot % nblk;
@@ -1375,148 +1413,132 @@ __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int
 #endif
   const MapSeq& ms = a.seq[b];
   const int n = ms.n_stack[CLS];
-  const long long per = CLS == 0 ? a.R * 120 : a.cap;
-  const long long sb = (long long)b * per;
+  const long long sb = (long long)b * (CLS == 0 ? a.R * 120 : a.cap);
   if (!ms.gate) return;
   double par[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
   const int H = a.grid_H[CLS];
-  const int* __restrict__ start = a.grid_start[CLS] + (long long)b * (H + 1);
-  const float4* __restrict__ sorted = a.grid_sorted[CLS] + (long long)b * a.pool_cap;
-  // Everything below is addressed as (wave-uniform per-sequence base) + (32-bit byte offset): one VGPR per address, no 64-bit lane math.
-  const char* __restrict__ sorted_b = reinterpret_cast<const char*>(sorted);
-  char* __restrict__ cand_b = reinterpret_cast<char*>(a.cand[CLS] + (long long)b * ((per + 63) >> 6) * ((K + 1) * 64));
-  char* __restrict__ qinfo_b = reinterpret_cast<char*>(a.qinfo[CLS] + sb);
+  const char* __restrict__ start_b = reinterpret_cast<const char*>(a.grid_start[CLS] + (long long)b * (H + 1));
+  const char* __restrict__ sorted_b = reinterpret_cast<const char*>(a.grid_sorted[CLS] + (long long)b * a.pool_cap);
   char* __restrict__ knn_b = reinterpret_cast<char*>(a.knn + (long long)b * a.cap * 4);
-  const char* __restrict__ start_b = reinterpret_cast<const char*>(start);
-  __shared__ int s_work[NT];
-  __shared__ int s_nwork;
-  auto point_at = [&](unsigned pos) -> float4 { return *reinterpret_cast<const float4*>(sorted_b + (pos << 4)); };
-  auto entry = [&](unsigned ofs) -> int& { return *reinterpret_cast<int*>(cand_b + ofs); };
-  // list row j of query i: int [(i >> 6) * (K + 1) * 64 + j * 64 + (i & 63)] of the sequence's lists; row K takes what overflows
-  auto list_of = [&](int i) { return (unsigned)(((i >> 6) * ((K + 1) * 64) + (i & 63)) << 2); };
-  auto store_knn = [&](int i, bool found, const float4* q) {
-    float4* out = reinterpret_cast<float4*>(knn_b + ((unsigned)i << 6));
-    if (found) {
-      out[0] = make_float4(q[0].x, q[0].y, q[0].z, 1.f);
-      out[1] = make_float4(q[1].x, q[1].y, q[1].z, q[2].x);
-      out[2] = make_float4(q[2].y, q[2].z, q[3].x, q[3].y);
-      out[3] = make_float4(q[3].z, q[4].x, q[4].y, q[4].z);
-    } else {
-      out[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __shared__ typename C::Lds lds[4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / G, l = lane % G;
+  typename C::Lds& W = lds[wave];
+  const unsigned below = (1u << l) - 1u;                                     // the lanes of my group in front of me
+  const int gshift = lane & ~(G - 1);
+
+  // rank of each of my OWN entries (e = l + G u < m) among the m keys of my group's list
+  auto ranks = [&](int m, unsigned long long* mine, int* rank) {
+#pragma unroll
+    for (int u = 0; u < OWN; ++u) { const int e = l + G * u; mine[u] = e < m ? W.key[grp][e] : ~0ull; rank[u] = 0; }
+    for (int j = 0; __any(j < m); ++j) {
+      const unsigned long long kj = j < m ? W.key[grp][j] : ~0ull;
+#pragma unroll
+      for (int u = 0; u < OWN; ++u) rank[u] += kj < mine[u] ? 1 : 0;
     }
   };
 
-  // the five neighbours out of the list (cnt <= K) -> knn
-  auto drain = [&](int i, const float4& sel, unsigned lst, int cnt) {
-    const mfloat2 sxy = {sel.x, sel.y};
-    Keys5 top;
-    top.init();
-    for (int j = 0; j < cnt; j += 2) {                                        // two entries in flight
-      const bool two = j + 1 < cnt;
-      const int p0 = entry(lst + (j << 8)), p1 = entry(lst + ((two ? j + 1 : j) << 8));
-      const float4 c0 = point_at(p0), c1 = point_at(p1);
-      const float d0 = dist_to_map(c0, sxy, sel.z), d1 = dist_to_map(c1, sxy, sel.z);
-      top.insert((unsigned long long)__float_as_uint(d0) << 32 | (unsigned)(__float_as_int(c0.w) << 5 | j));
-      top.insert((unsigned long long)(two ? __float_as_uint(d1) : 0x7f800000u) << 32 | (unsigned)(__float_as_int(c1.w) << 5 | (j + 1)));
+  for (int base = (blk * 4 + wave) * 64; base < n; base += nblk * 256) {     // 64 consecutive stack points per wave and trip
+    const int i = base + lane;
+    {
+      float4 sel = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < n) sel = associate_to_map(a.stack[CLS][sb + i], par);          // pointSel (:580, :646)
+      W.sel[lane] = make_float4(sel.x, sel.y, sel.z, i < n ? 1.f : 0.f);
     }
-    const bool found = (unsigned)(top.t[4] >> 32) < 0x3f800000u;              // pointSearchSqDis[4] < 1.0
-    float4 q[5];
-    if (found) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int p = 0; p < G; ++p) {
+      const int q = p * NQ + grp;                                              // my group's query (of the wave's 64)
+      const float4 sel = W.sel[q];
+      const bool qlive = sel.w != 0.f;
+      const mfloat2 sxy = {sel.x, sel.y};
+      {
+        // heads of the eight buckets of the 2x2x2 block: lane l of the group fetches bucket l (and l + 4 when G = 4)
+        const float gx = sel.x * kMapCellInv, gy = sel.y * kMapCellInv, gz = sel.z * kMapCellInv;
+        const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
+        const int nx = gx - (float)cx >= 0.5f ? cx + 1 : cx - 1, ny = gy - (float)cy >= 0.5f ? cy + 1 : cy - 1, nz = gz - (float)cz >= 0.5f ? cz + 1 : cz - 1;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) q[k] = point_at(entry(lst + (((unsigned)top.t[k] & 31u) << 8)));
-    }
-    store_knn(i, found, q);
-  };
-
-  // walk the block of query i: make its list, then drain it (or, on overflow, walk again in the direct form)
-  auto full = [&](int i, const float4& sel) {
-    const mfloat2 sxy = {sel.x, sel.y};
-    const MapBlock k = map_block(sel.x, sel.y, sel.z);
-    // hash terms and local bits of the two cells per axis, then the eight combinations (map_bucket(), spelled out)
-    const unsigned hx0 = (unsigned)(k.cx >> kMapLocalBits) * 73856093u, hx1 = (unsigned)(k.nx >> kMapLocalBits) * 73856093u;
-    const unsigned hy0 = (unsigned)(k.cy >> kMapLocalBits) * 19349663u, hy1 = (unsigned)(k.ny >> kMapLocalBits) * 19349663u;
-    const unsigned hz0 = (unsigned)(k.cz >> kMapLocalBits) * 83492791u, hz1 = (unsigned)(k.nz >> kMapLocalBits) * 83492791u;
-    const unsigned px0 = map_local_bits(k.cx, 0), px1 = map_local_bits(k.nx, 0), py0 = map_local_bits(k.cy, 1), py1 = map_local_bits(k.ny, 1), pz0 = map_local_bits(k.cz, 2), pz1 = map_local_bits(k.nz, 2);
-    int s0[8], s1[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {                                            // the 8 bucket heads first: independent 8-byte loads
-      const unsigned h = ((((c & 1) ? hx1 : hx0) ^ ((c & 2) ? hy1 : hy0) ^ ((c & 4) ? hz1 : hz0)) << (3 * kMapLocalBits) | (((c & 1) ? px1 : px0) | ((c & 2) ? py1 : py0) | ((c & 4) ? pz1 : pz0))) & (unsigned)(H - 1);
-      const MapIntPair v = *reinterpret_cast<const MapIntPair*>(start_b + (h << 2));
-      s0[c] = v.a; s1[c] = v.b;
-    }
-    // The eight cells sit in eight different buckets (map_bucket).  Points of OTHER cells hashed into one of them need no test of their
-    // own: they are real map points, and a list (or the direct form) holding more real points than needed changes nothing — the drain
-    // keeps d < 1 only, and every point with d < 1 is in the block.
-    const unsigned lst = list_of(i);
-    constexpr int U = ALOAM_MAP_SEARCH_U;                                    // independent loads in flight per lane
-    int cnt = 0;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      for (int kk = s0[c]; kk < s1[c]; kk += U) {
-        const int m = s1[c] - kk;
-        float4 p[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = point_at(u < m ? kk + u : kk);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const float d = dist_to_map(p[u], sxy, sel.z);
-          if (u < m && d < kMapListR2) { entry(lst + ((cnt < K ? cnt : K) << 8)) = kk + u; ++cnt; }
+        for (int c0 = 0; c0 < 8; c0 += G) {
+          const int c = c0 + l;
+          const unsigned h = map_bucket((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz, H);
+          int2 v = make_int2(0, 0);
+          if (qlive) { const MapIntPair t = *reinterpret_cast<const MapIntPair*>(start_b + (h << 2)); v = make_int2(t.a, t.b); }
+          W.hd[grp][c] = v;
         }
       }
-    }
-    *reinterpret_cast<float4*>(qinfo_b + ((unsigned)i << 4)) = make_float4(sel.x, sel.y, sel.z, __int_as_float(cnt));
-    if (first) { MAP_STAT(0, 1); MAP_STAT(1, cnt); if (cnt > K) MAP_STAT(2, 1); } else MAP_STAT(4, 1);
-    if (cnt <= K) { drain(i, sel, lst, cnt); return; }
-    // direct form (a query with more than K map points inside 1.1 m): every candidate inserted at once, neighbours by submap index
-    Keys5 top;
-    top.init();
+      __builtin_amdgcn_wave_barrier();
+      int kc[8], ke[8];                                                        // my next entry and the end of every bucket
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      for (int kk = s0[c]; kk < s1[c]; ++kk) {
-        const float4 p = point_at(kk);
-        top.insert((unsigned long long)__float_as_uint(dist_to_map(p, sxy, sel.z)) << 32 | (unsigned)(__float_as_int(p.w) << 5));
+      for (int c = 0; c < 8; ++c) { const int2 v = W.hd[grp][c]; kc[c] = v.x + l; ke[c] = v.y; }
+      int cnt = 0;
+      // Every point closer than 1 m lies in one of the eight cells, the eight cells sit in eight different buckets (map_bucket), and a
+      // point of another cell hashed into one of them fails d < 1: the lists hold exactly the neighbours within 1 m, each once.
+      for (;;) {
+        bool more = false;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) more = more || kc[c] < ke[c];
+        if (!__any(more)) break;
+        float4 pt[8];                                                          // all eight loads in flight, unconditionally (a lane beyond its
+#pragma unroll                                                                 // bucket reads entry 0: one line for all of them)
+        for (int c = 0; c < 8; ++c) pt[c] = *reinterpret_cast<const float4*>(sorted_b + ((unsigned)(kc[c] < ke[c] ? kc[c] : 0) << 4));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          if (!__any(kc[c] < ke[c])) continue;
+          if (__any(cnt > K - G)) {                                            // a list could overflow in this step: cut it down to its five smallest
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long mine[OWN]; int rank[OWN]; float mx[OWN], my[OWN], mz[OWN];
+            ranks(cnt, mine, rank);
+#pragma unroll
+            for (int u = 0; u < OWN; ++u) { const int e = l + G * u < cnt ? l + G * u : 0; mx[u] = W.xyz[grp][e][0]; my[u] = W.xyz[grp][e][1]; mz[u] = W.xyz[grp][e][2]; }
+            __builtin_amdgcn_wave_barrier();
+            if (cnt > K - G) {
+#pragma unroll
+              for (int u = 0; u < OWN; ++u)
+                if (l + G * u < cnt && rank[u] < 5) { W.key[grp][rank[u]] = mine[u]; W.xyz[grp][rank[u]][0] = mx[u]; W.xyz[grp][rank[u]][1] = my[u]; W.xyz[grp][rank[u]][2] = mz[u]; }
+              cnt = 5;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+          const float d = dist_to_map(pt[c], sxy, sel.z);                      // FLANN L2_Simple, f32
+          const bool acc = kc[c] < ke[c] && d < 1.0f;
+          const unsigned bits = (unsigned)(__ballot(acc) >> gshift) & ((1u << G) - 1u);
+          if (acc) {
+            const int pos = cnt + __builtin_popcount(bits & below);
+            W.key[grp][pos] = (unsigned long long)__float_as_uint(d) << 32 | (unsigned)__float_as_int(pt[c].w);
+            W.xyz[grp][pos][0] = pt[c].x; W.xyz[grp][pos][1] = pt[c].y; W.xyz[grp][pos][2] = pt[c].z;
+          }
+          cnt += __builtin_popcount(bits);
+          kc[c] += G;
+        }
       }
-    const bool found = (unsigned)(top.t[4] >> 32) < 0x3f800000u;
-    float4 q[5];
-    if (found) {
-      const int* tab = a.tab + (long long)b * kTabInts;
+      __builtin_amdgcn_wave_barrier();
+      // the five smallest keys in order -> the query's 64-byte record {x0 y0 z0 found | x1 y1 z1 x2 | y2 z2 x3 y3 | z3 x4 y4 z4}
+      {
+        unsigned long long mine[OWN]; int rank[OWN];
+        ranks(cnt, mine, rank);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) q[j] = submap_point(a, b, CLS, tab, ms.n_valid, (int)((unsigned)top.t[j] >> 5));
+        for (int u = 0; u < OWN; ++u) {
+          const int e = l + G * u;
+          if (e < cnt && rank[u] < 5) {
+            const int o = rank[u] == 0 ? 0 : 3 * rank[u] + 1;
+            W.out[grp][o] = W.xyz[grp][e][0]; W.out[grp][o + 1] = W.xyz[grp][e][1]; W.out[grp][o + 2] = W.xyz[grp][e][2];
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (l == 0) W.out[grp][3] = cnt >= 5 ? 1.f : 0.f;                      // pointSearchSqDis[4] < 1.0  <=>  five points within 1 m
+        __builtin_amdgcn_wave_barrier();
+        if (qlive) {
+          char* rec = knn_b + ((unsigned)(base + q) << 6);
+          if (G == 8) *reinterpret_cast<float2*>(rec + l * 8) = *reinterpret_cast<const float2*>(&W.out[grp][2 * l]);
+          else *reinterpret_cast<float4*>(rec + l * 16) = *reinterpret_cast<const float4*>(&W.out[grp][4 * l]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
     }
-    store_knn(i, found, q);
-  };
-
-  for (int base = blk * NT; base < n; base += nblk * NT) {                   // grid-stride over the stack, uniform per workgroup
-    const int i = base + (int)threadIdx.x;
-    if (first) {
-      if (i < n) full(i, associate_to_map(a.stack[CLS][sb + i], par));       // pointSel (:580, :646)
-      continue;
-    }
-    if (threadIdx.x == 0) s_nwork = 0;
-    __syncthreads();
-    if (i < n) {
-      const float4 sel = associate_to_map(a.stack[CLS][sb + i], par);
-      const float4 q1 = *reinterpret_cast<const float4*>(qinfo_b + ((unsigned)i << 4));
-      const int cnt = __float_as_int(q1.w);
-      const float sx = sel.x - q1.x, sy = sel.y - q1.y, sz = sel.z - q1.z;
-      const MapBlock k1 = map_block(q1.x, q1.y, q1.z), k2 = map_block(sel.x, sel.y, sel.z);
-      const bool same = ((k1.cx ^ k2.cx) | (k1.cy ^ k2.cy) | (k1.cz ^ k2.cz) | (k1.nx ^ k2.nx) | (k1.ny ^ k2.ny) | (k1.nz ^ k2.nz)) == 0;
-      MAP_STAT(3, 1);
-      if (same && (sx * sx + sy * sy) + sz * sz < kMapReuseShift2 && cnt <= K) { MAP_STAT(5, cnt); drain(i, sel, list_of(i), cnt); }
-      else s_work[atomicAdd(&s_nwork, 1)] = i;
-    }
-    __syncthreads();
-    const int nw = s_nwork;
-    for (int w = threadIdx.x; w < nw; w += NT) {
-      const int j = s_work[w];
-      full(j, associate_to_map(a.stack[CLS][sb + j], par));
-    }
-    __syncthreads();
   }
 }
-#endif  // ALOAM_MAP_SEARCH_V2
+#endif  // ALOAM_MAP_SEARCH_COOP
 
 // Fit half: line fit (corner) / plane fit (surf) in f64 on the five neighbours, validity tests, factor record.
 template <int CLS>
@@ -1948,13 +1970,13 @@ void launch_map_grid(const MapArgs& a, hipStream_t s) {
 }
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;                      // padded so that every (XCD, sequence slot) pair exists
-  const int first = iter == 0 ? 1 : 0;                   // the lists of iteration 0 serve the later ones (k_map_search)
+  (void)iter;
 #ifndef ALOAM_MAP_DEBUG_LDS
 #define ALOAM_MAP_DEBUG_LDS 0      // occupancy experiments: dynamic LDS bytes per search workgroup (nothing uses them)
 #endif
-  hipLaunchKernelGGL(k_map_search<0>, dim3(ALOAM_MAP_SEARCH_NBLK0 * by), dim3(kMapSearchThreads), ALOAM_MAP_DEBUG_LDS, s, a, ALOAM_MAP_SEARCH_NBLK0, first);
+  hipLaunchKernelGGL(k_map_search<0>, dim3(ALOAM_MAP_SEARCH_NBLK0 * by), dim3(kMapSearchThreads), ALOAM_MAP_DEBUG_LDS, s, a, ALOAM_MAP_SEARCH_NBLK0);
   hipLaunchKernelGGL(k_map_fit<0>, dim3(16, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_map_search<1>, dim3(ALOAM_MAP_SEARCH_NBLK1 * by), dim3(kMapSearchThreads), ALOAM_MAP_DEBUG_LDS, s, a, ALOAM_MAP_SEARCH_NBLK1, first);
+  hipLaunchKernelGGL(k_map_search<1>, dim3(ALOAM_MAP_SEARCH_NBLK1 * by), dim3(kMapSearchThreads), ALOAM_MAP_DEBUG_LDS, s, a, ALOAM_MAP_SEARCH_NBLK1);
   hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) {
@@ -1971,6 +1993,3 @@ void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s) {
 void launch_map_register(const MapArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_map_register, dim3((a.cap + 255) / 256, a.B), dim3(256), 0, s, a); }
 
 }  // namespace aloam
-#ifdef ALOAM_MAP_STATS
-extern "C" int aloam_debug_map_stats(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(aloam::g_map_stats), sizeof(unsigned long long) * 16); }
-#endif

@@ -6,7 +6,6 @@ namespace aloam {
 
 constexpr int kMapW = 21, kMapH = 21, kMapD = 11, kMapCubes = kMapW * kMapH * kMapD;   // reference src/laserMapping.cpp:75-80
 constexpr int kMapValidMax = 75;                                                       // 5 x 5 x 3 window (:512-529)
-constexpr int kMapListK0 = 32, kMapListK1 = 16;                                         // rows of a candidate list, corner / surf class (<= 32: the slot sits in 5 bits of the key)
 constexpr int kVoxTile = 2048;                                                         // keys per sort tile (general path)
 constexpr int kVoxTinyN = 2048, kVoxSmallN = 8192, kVoxBigN = 65536;                                    // segment sizes the single-workgroup LDS filter takes (256 / 1024 threads)
 
@@ -90,8 +89,6 @@ struct MapArgs {
   int* grid_cnt[2];              // [B][H]
   int grid_H[2];
   float4* knn;                   // [B][cap][4]  the five neighbours of every stack point (search -> fit)
-  int* cand[2];                  // [B][ceil(per / 64)][K + 1][64]  candidate lists of the stack points (k_map_search), per = R*120 / cap
-  float4* qinfo[2];              // [B][per]  where a point's list was made (x, y, z) and its length
   MapEdgeRec* edges;             // [B][R*120]
   MapNormRec* norms;             // [B][cap]
   int lm_max_iterations;

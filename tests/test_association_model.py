@@ -228,42 +228,13 @@ def _bits(d):
     return int(np.array([d], np.float32).view(np.uint32)[0])
 
 
-def _map_walk(sel, pts, buckets, H, K):
-    """k_map_search `full`: the positions of all candidates of the 2x2x2 block closer than 1.1 m, in walk order (list rows 0..K-1;
-    the count runs on past K).  A `position` here is (bucket, slot) flattened = index into the bucket-sorted array."""
-    c, nb = _map_block(sel)
-    lst, cnt = [], 0
-    hs = []
-    for m in range(8):
-        h = _map_bucket(nb[0] if m & 1 else c[0], nb[1] if m & 2 else c[1], nb[2] if m & 4 else c[2], H)
-        hs.append(h)
-        for i in buckets[h]:
-            if _d2(pts[i], sel) < F(1.21):
-                if cnt < K:
-                    lst.append(i)
-                cnt += 1
-    assert len(set(hs)) == 8, "the eight cells of a block must sit in eight different buckets"
-    return lst, cnt, hs
-
-
-def _map_drain(sel, pts, lst):
-    t = [0x3F800000 << 32] * 5
-    for j, i in enumerate(lst):
-        t = _keys5_insert(t, _bits(_d2(pts[i], sel)) << 32 | i << 5 | j)
-    if (t[4] >> 32) >= 0x3F800000:
-        return None
-    return [lst[k & 31] for k in t]
-
-
 def test_map_search_block_model_equals_brute_force():
     """k_map_search, round 5 (a-loam_amd/csrc/mapping_kernels.hip): 2 m cells whose buckets carry the cell parities in their low
-    bits (the eight cells of the 2x2x2 block on the query's side never share a bucket: no duplicate test), the walk only lists the
-    candidates closer than 1.1 m, a branch-free insertion of packed (distance, index, slot) keys drains the list — must give
-    exactly the five smallest (distance, index) among the points with d < 1 m, or nothing when there are fewer than five, which is
-    what the reference uses of nearestKSearch(k = 5) (src/laserMapping.cpp:582,650).  And the list of a query serves a MOVED query
-    (second LM iteration) whenever it moved < 0.099 m and kept its block; the kernel walks again otherwise."""
+    bits (the eight cells of the 2x2x2 block on the query's side never share a bucket: no duplicate test), no per-candidate cell test,
+    the five smallest kept as packed (distance bits << 32 | index) keys by a branch-free insertion with the entry's position beside
+    them — must give exactly the five smallest (distance, index) among the points with d < 1 m, or nothing when there are fewer than
+    five, which is what the reference uses of nearestKSearch(k = 5) (src/laserMapping.cpp:582,650)."""
     rng = np.random.default_rng(11)
-    reused = walked = 0
     for H in (8, 64, 4096):
         n = 3000
         pts = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
@@ -276,30 +247,23 @@ def test_map_search_block_model_equals_brute_force():
             rng.shuffle(bk)                                                    # the LDS counting sort fills a bucket in no particular order
         qs = np.concatenate([pts[rng.integers(0, n, 150)] + rng.normal(scale=0.3, size=(150, 3)).astype(np.float32),
                              np.round(rng.uniform(-9, 9, (50, 3)) * 2).astype(np.float32) / 2]).astype(np.float32)
-
-        def brute(sel):
-            w = sorted((float(_d2(p, sel)), i) for i, p in enumerate(pts) if _d2(p, sel) < F(1.0))[:5]
-            return [i for _, i in w] if len(w) == 5 else None
-
         for sel in qs:
-            K = 32
-            lst, cnt, _ = _map_walk(sel, pts, buckets, H, K)
-            if cnt <= K:
-                assert _map_drain(sel, pts, lst) == brute(sel), (H, sel)
-            # second iteration: the query moved by a pose correction
-            for scale in (0.003, 0.03, 0.2):
-                sel2 = (sel + rng.normal(scale=scale, size=3)).astype(np.float32)
-                sh = F(F(F(sel2[0] - sel[0]) ** 2 + F(sel2[1] - sel[1]) ** 2) + F(sel2[2] - sel[2]) ** 2)
-                if _map_block(sel) == _map_block(sel2) and sh < F(0.099) * F(0.099) and cnt <= K:
-                    assert _map_drain(sel2, pts, lst) == brute(sel2), (H, sel, sel2)
-                    reused += 1
-                else:
-                    walked += 1
-    assert reused > 500 and walked > 200, (reused, walked)
-    # a short list (K = 4) overflows: the kernel's direct form is the plain definition, nothing to model; the count must say so
-    sel = pts[0]
-    lst, cnt, _ = _map_walk(sel, pts, buckets, 4096, 4)
-    assert len(lst) == min(cnt, 4)
+            c, nb = _map_block(sel)
+            hs = [_map_bucket(nb[0] if m & 1 else c[0], nb[1] if m & 2 else c[1], nb[2] if m & 4 else c[2], H) for m in range(8)]
+            assert len(set(hs)) == 8, "the eight cells of a block must sit in eight different buckets"
+            t, pos = [0x3F800000 << 32] * 5, [None] * 5
+            for h in hs:
+                for i in buckets[h]:
+                    d = _d2(pts[i], sel)
+                    if d < F(1.0):                                             # the kernel's wave-level skip; the sentinel alone would do
+                        key = _bits(d) << 32 | i
+                        cmp = [key < x for x in t]
+                        t = _keys5_insert(t, key)
+                        pos = [i if cmp[0] else pos[0]] + [pos[k - 1] if cmp[k - 1] else (i if cmp[k] else pos[k]) for k in range(1, 5)]
+            found = pos if (t[4] >> 32) < 0x3F800000 else None
+            w = sorted((float(_d2(p, sel)), i) for i, p in enumerate(pts) if _d2(p, sel) < F(1.0))[:5]
+            want = [i for _, i in w] if len(w) == 5 else None
+            assert found == want, (H, sel, found, want)
 
 
 def test_keys5_insertion_is_a_sorted_top_five():

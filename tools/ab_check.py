@@ -149,13 +149,6 @@ def run(argv):
         for cls in (0, 1):
             q = max(1, st[cls * 32 + 1])
             print("corner" if cls == 0 else "plane", {names[i]: round(st[cls * 32 + i] / q, 3) for i in sorted(names)}, "queries", st[cls * 32 + 1])
-    if hasattr(L, "aloam_debug_map_stats"):                     # -DALOAM_MAP_STATS builds: what the submap search did
-        st = (C.c_ulonglong * 16)()
-        L.aloam_debug_map_stats(st)
-        for cls in (0, 1):
-            v = [int(st[cls * 8 + i]) for i in range(8)]
-            print("map search", "corner" if cls == 0 else "surf", {"queries it0": v[0], "list entries per query": round(v[1] / max(1, v[0]), 2), "overflows": v[2],
-                  "queries it1+": v[3], "walked again": v[4], "walked again %": round(100 * v[4] / max(1, v[3]), 2), "entries drained per reusing query": round(v[5] / max(1, v[3] - v[4]), 2)})
     gpu.close()
     hip.free(base)
     print(lib_path, "->", out_path, "kernel ms per step:", round(sum(v["total_ms"] for v in prof.values()) / steps, 3))
