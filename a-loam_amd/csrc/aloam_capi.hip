@@ -51,6 +51,7 @@ struct aloam_ctx {
   int *d_hist = nullptr, *d_blockoff = nullptr, *d_ringstart = nullptr;
   float4* d_cloud = nullptr; float* d_curv = nullptr; int8_t* d_label = nullptr;
   unsigned long long* d_lookback = nullptr; unsigned reg_epoch = 0;   // ring-count granules of k_ring_features, launch counter
+  int* d_ring_ticket = nullptr;                                       // per sweep: rings handed out to the workgroups of the running k_ring_features
   bool debug_arrays = false;                                         // the last registration wrote curvature / labels
   float4 *d_sharp = nullptr, *d_flat = nullptr;
   float4* d_less_sharp[2] = {nullptr, nullptr};
@@ -166,7 +167,7 @@ RegArgs reg_args(aloam_ctx* c, const void* d_scans, long long seq_stride, int pt
   a.ring_from_field = c->cfg.ring_from_field; a.min_range = c->cfg.min_range;
   a.meta = c->d_meta; a.ringid = c->d_ringid; a.ori = c->d_ori; a.hist = c->d_hist; a.blockoff = c->d_blockoff;
   a.ringstart = c->d_ringstart; a.cloud = c->d_cloud; a.curv = c->d_curv; a.label = c->d_label;
-  a.lookback = c->d_lookback; a.epoch = c->reg_epoch; a.store_debug = c->debug_arrays ? 1 : 0;
+  a.lookback = c->d_lookback; a.epoch = c->reg_epoch; a.store_debug = c->debug_arrays ? 1 : 0; a.ring_ticket = c->d_ring_ticket;
   a.sharp = c->d_sharp; a.less_sharp = c->d_less_sharp[c->cur]; a.flat = c->d_flat; a.less_flat = c->d_less_flat[c->cur];
   return a;
 }
@@ -311,6 +312,7 @@ int aloam_create_stages(const aloam_config* cfg, int stages, aloam_ctx** out) {
     if ((rc = dmalloc(c, &c->d_curv, B * cap))) return rc;
     if ((rc = dmalloc(c, &c->d_label, B * cap))) return rc;
     if ((rc = dmalloc(c, &c->d_lookback, B * 4 * R))) return rc;
+    if ((rc = dmalloc(c, &c->d_ring_ticket, B))) return rc;
   }
   if (reg || odo) {
     if ((rc = dmalloc(c, &c->d_sharp, B * R * 12))) return rc;
@@ -357,7 +359,7 @@ void aloam_destroy(aloam_ctx* c) {
   for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
   void* bufs[] = {c->d_in[0], c->d_in[1], c->d_nin, c->d_meta, c->d_ringid, c->d_ori, c->d_hist, c->d_blockoff, c->d_ringstart, c->d_cloud, c->d_curv,
-                  c->d_label, c->d_lookback, c->d_sharp,
+                  c->d_label, c->d_lookback, c->d_ring_ticket, c->d_sharp,
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes, c->d_sel_sharp, c->d_sel_flat,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
                   c->d_grid_start2[0], c->d_grid_start2[1],
@@ -541,14 +543,24 @@ int aloam_odometry_step(aloam_ctx* c) {
     // so the path is kept (tested bit for bit) but off by default.
     hipGraphExec_t& ge = c->odom_graph[c->cur];
     if (!ge) {
+      // A failed capture must not leave the stream in capture mode or leak the graph: the capture is always ended, the graph always
+      // destroyed, and on any error this context goes back to separate launches for good (the step itself is then launched normally).
       hipGraph_t g = nullptr;
-      HIP_TRY(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-      launch_all();
-      HIP_TRY(c, hipStreamEndCapture(c->stream, &g));
-      HIP_TRY(c, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
-      (void)hipGraphDestroy(g);
+      hipError_t e = hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal);
+      if (e == hipSuccess) {
+        launch_all();
+        e = hipStreamEndCapture(c->stream, &g);                  // launch errors inside the capture surface here
+        if (e == hipSuccess) e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        if (g) (void)hipGraphDestroy(g);
+      }
+      if (e != hipSuccess) {
+        (void)hipGetLastError();                                 // clear the sticky capture error; the cause is not lost: the plain launches below report theirs
+        if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
+        c->use_graph = false;
+      }
     }
-    HIP_TRY(c, hipGraphLaunch(ge, c->stream));
+    if (ge) HIP_TRY(c, hipGraphLaunch(ge, c->stream));
+    else launch_all();
   } else {
     launch_all();
   }

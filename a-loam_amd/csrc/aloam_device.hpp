@@ -66,6 +66,7 @@ struct RegArgs {
   int8_t* label;             // [B][cap]
   unsigned long long* lookback;   // [B][4][R] {launch epoch, count} granules: points per ring and output class (k_ring_features)
   unsigned epoch;            // this launch; never 0 (the buffer starts zeroed)
+  int* ring_ticket;          // [B] rings of the sweep handed out so far (k_ring_features takes, k_cloud_sizes resets)
   int store_debug;           // 1: also write curv / label (parity tests); the throughput entries leave them out
   float4* sharp;             // [B][R*12]
   float4* less_sharp;        // [B][R*120]   (current buffer)

@@ -139,7 +139,8 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
   if (n_edges + n_planes == 0) {
     termination = 4;
   } else if (!isfinite(cost) || !all_finite(acc, 27)) {
-    termination = 5;              // Ceres: "Residual and Jacobian evaluation failed" (non-finite residual or Jacobian: J^T J / J^T r not finite), parameters untouched
+    termination = 5;              // Ceres: "Residual and Jacobian evaluation failed" (non-finite residual or Jacobian: J^T J / J^T r not finite — the sums,
+                                  // see the note at the accepted step), parameters untouched
   } else {
     double H[6][6], g[6], scale[6];
     auto unpack = [&](const double* s) {
@@ -172,7 +173,7 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
     while (true) {
       if (iter >= lm_max_iterations) { termination = 0; break; }
       if (gmax <= kGradientTol) { termination = 3; break; }
-      if (radius < kMinRadius) { termination = 5; break; }
+      if (radius <= kMinRadius) { termination = 6; break; }   // Ceres: MinTrustRegionRadiusReached(), `<=`, CONVERGENCE (not reachable in 4 iterations from 1e4)
       ++iter;
       iterations = iter;
       if (!reuse_diagonal) for (int c = 0; c < 6; ++c) diag[c] = fmin(fmax(H[c][c], kMinDiag), kMaxDiag);
@@ -219,10 +220,14 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
         x_norm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
         for (int k = 0; k < 28; ++k) acc[k] = cacc[k];
         cost = acc[27];
+        ++successful;
+        // HandleSuccessfulStep(): x is the candidate now; a Jacobian that cannot be evaluated there ends the solve as FAILURE.  (The sums
+        // are tested, not the entries: a finite entry beyond ~1e154 overflows in J^T J and reads as non-finite here, where Ceres, the
+        // oracle and the shim would go on — no real sweep comes within 150 orders of magnitude of that.)
+        if (!all_finite(acc, 28)) { termination = 5; break; }
         unpack(acc);
         gmax = gradient_max();
         apply_scale();
-        ++successful;
         const double c3 = 2.0 * rel - 1.0;
         radius = radius / fmax(1.0 / 3.0, 1.0 - c3 * c3 * c3);
         radius = fmin(kMaxRadius, radius);

@@ -877,8 +877,13 @@ __device__ __forceinline__ float dist_to(const float4& p, float2v sxy, float sz)
 template <bool HALVES, int kRows, class F>
 __device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsigned last_index, int s0, int cnt, int lane, int last4, int* lds, F&& f, bool* single_round = nullptr, int* rows_first = nullptr, int stat_cls = 0, int stat_slot = -1) {
   constexpr int W = HALVES ? 32 : 64, LOGW = HALVES ? 5 : 6, kSlots = HALVES ? 2 * kRows : kRows;
+  static_assert(kRows <= 8, "the mark slots of a round are zeroed by one store of the wave: 4 * kSlots <= 64 lanes");
   unsigned* marks = reinterpret_cast<unsigned*>(lds);
   int* table = lds + kRows * 8;
+  // A lane past the end of its half's list reads table[rank] of a rank no bucket owns: zero the table once per call, so that such a lane
+  // looks at the (clamped) entry `position` of the cloud — a real point, a harmless extra candidate — and never at an uninitialised word.
+  table[lane] = 0;
+  if (lane < 8) table[64 + lane] = 0;
   const int h = HALVES ? lane >> 5 : 0, l = lane & (W - 1);
   const int incl = HALVES ? half_scan_i32<false>(cnt) : wave_scan_i32<false>(cnt);
   int total, tmax;
@@ -955,7 +960,8 @@ __device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsign
 #ifndef ALOAM_PAIR_ROWS_WIDE
 #define ALOAM_PAIR_ROWS_WIDE 8
 #endif
-template <bool PLANE, bool WIDE> struct PairRows { static constexpr int value = WIDE ? (PLANE ? ALOAM_PAIR_ROWS_WIDE : ALOAM_PAIR_ROWS_PLANE) : (PLANE ? ALOAM_PAIR_ROWS_PLANE : ALOAM_PAIR_ROWS_CORNER); };
+template <bool PLANE, bool WIDE> struct PairRows { static constexpr int value = WIDE ? (PLANE ? ALOAM_PAIR_ROWS_WIDE : ALOAM_PAIR_ROWS_PLANE) : (PLANE ? ALOAM_PAIR_ROWS_PLANE : ALOAM_PAIR_ROWS_CORNER);
+                                                   static_assert(value >= 1 && value <= 8, "ALOAM_PAIR_ROWS_*: 1 .. 8 rows (sweep2's mark slots)"); };
 
 __device__ __forceinline__ unsigned long long nn_key(float d, unsigned wb) { return ((unsigned long long)__float_as_uint(d) << 32) | ((wb & kIdxMask) << 12) | (wb >> 20); }
 __device__ __forceinline__ void take_min(unsigned long long& t, unsigned long long v) { t = v < t ? v : t; }

@@ -308,13 +308,15 @@ __device__ __forceinline__ unsigned wave_extreme_u32(unsigned v, int lane) {
 // workgroup publishes its own count per class as ONE 8-byte granule {launch epoch, count}: the value is its own flag, nothing has
 // to be reset between launches, and a reader needs no other data of the writer (MI355X_MICROARCH.md, inter-workgroup visibility:
 // agent-scope loads of 8-byte granules).  A reader gathers the granules of the rings in front of it with one wave (lane = ring)
-// and sums them: no serial ripple from ring to ring.  A workgroup only waits for workgroups with a lower linear id, and those are
-// dispatched first on this hardware (an assumption about the dispatcher; the wait below is bounded in case it breaks).
+// and sums them: no serial ripple from ring to ring.  WHICH ring a workgroup works on is decided when it starts executing: it takes
+// the next ticket of its sweep (k_ring_features), so ring r of a sweep is always in the hands of a workgroup that started before the
+// one holding ring r + 1 — a workgroup only ever waits for workgroups that are already running, whatever order the dispatcher
+// launches them in (round 4 used blockIdx.y and relied on in-order dispatch).  No deadlock: the unfinished workgroup with the smallest
+// ticket of a sweep waits for nobody; the wait is still bounded, as a trap for faults.
 __device__ __forceinline__ void publish_count(unsigned long long* slot, unsigned epoch, int count) {
   __hip_atomic_store(slot, ((unsigned long long)epoch << 32) | (unsigned)count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// The wait is bounded: in-order dispatch is what makes it free today, but it is not something HIP promises, and a fault in an
-// earlier ring's workgroup must not hang the stream.  After kGatherSpinLimit polls (~1 s) the lane gives up, the count reads 0 and
+// The wait is bounded: a fault in an earlier ring's workgroup must not hang the stream.  After kGatherSpinLimit polls (~1 s) the lane gives up, the count reads 0 and
 // kErrInternal is raised in the sequence's SeqMeta.err (aloam_synchronize reports it).
 constexpr int kGatherSpinLimit = 1 << 20;
 __device__ __forceinline__ int gather_counts(const unsigned long long* slots, int upto, unsigned epoch, int lane, int* err) {   // whole wave
@@ -710,11 +712,23 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
   return n_vox;
 }
 
+#ifndef ALOAM_RF_TICKET
+#define ALOAM_RF_TICKET 1       // A/B builds: 0 = ring from blockIdx.y (rounds 2 - 4: correct only while workgroups start in linear order)
+#endif
 template <int NPAD>
 __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int MAXN = NPAD + 11;
   constexpr int ITEMS = (MAXN + 255) / 256;
-  const int r = blockIdx.y, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // ring-major over the batch, see voxel_runs_tail
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // ring-major over the batch, see voxel_runs_tail
+#if ALOAM_RF_TICKET
+  // the ring of this workgroup = the next ticket of its sweep (see "output offsets across the rings of a sweep" above)
+  __shared__ int s_ticket;
+  if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.ring_ticket + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int r = __builtin_amdgcn_readfirstlane(s_ticket);
+#else
+  const int r = blockIdx.y;
+#endif
   const int start = a.ringstart[b * (a.R + 1) + r];
   const int n = a.ringstart[b * (a.R + 1) + r + 1] - start;
   unsigned long long* lb = a.lookback + (long long)b * 4 * a.R;             // [class][ring] count granules of this sweep
@@ -1044,7 +1058,7 @@ __global__ __launch_bounds__(64) void k_cloud_sizes(RegArgs a) {
   int* err = &a.meta[b].err;
   const int n0 = gather_counts(lb + 0 * a.R, a.R, a.epoch, lane, err), n1 = gather_counts(lb + 1 * a.R, a.R, a.epoch, lane, err);
   const int n2 = gather_counts(lb + 2 * a.R, a.R, a.epoch, lane, err), n3 = gather_counts(lb + 3 * a.R, a.R, a.epoch, lane, err);
-  if (lane == 0) { a.meta[b].n_sharp = n0; a.meta[b].n_less_sharp = n1; a.meta[b].n_flat = n2; a.meta[b].n_less_flat = n3; }
+  if (lane == 0) { a.meta[b].n_sharp = n0; a.meta[b].n_less_sharp = n1; a.meta[b].n_flat = n2; a.meta[b].n_less_flat = n3; a.ring_ticket[b] = 0; }   // tickets for the next launch
 }
 
 // -------------------------------------------------------------------------------------------------------

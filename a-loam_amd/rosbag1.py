@@ -112,7 +112,16 @@ def _records(buf: bytes, what: str) -> Iterator[Tuple[Dict[str, bytes], bytes, i
 
 def _file_records(f, what: str) -> Iterator[Tuple[Dict[str, bytes], bytes, int]]:
     """The same over a file object, one record in memory at a time (a KITTI sequence written as a bag is 10 - 20 GB)."""
+    import os
+    try:
+        size = os.fstat(f.fileno()).st_size
+    except (AttributeError, OSError, ValueError):       # not a real file (BytesIO ...): fall back to the length check after the read
+        size = None
+
     def need(n, start, part):
+        # a corrupt length word must not be handed to read() (a garbage 32-bit length is a 4 GiB allocation): compare it with what is left
+        if size is not None and n > size - f.tell():
+            raise BagError(f"truncated {what}: record {part} of {n} bytes at byte {start} runs past the end of the file")
         b = f.read(n)
         if len(b) != n:
             raise BagError(f"truncated {what}: record {part} cut off at byte {start}")
@@ -135,7 +144,9 @@ def _time_ns(v: bytes) -> int:
 
 
 def read_messages(path: str, topics: Optional[List[str]] = None) -> Iterator[Tuple[str, str, int, bytes]]:
-    """Yields (topic, message type, bag time in ns, serialised message) in file order (= recording order)."""
+    """Yields (topic, message type, bag time in ns, serialised message) in file order (= recording order).  The file stays open while
+    the generator lives: a caller that stops early should close() the generator (or wrap it in contextlib.closing) rather than wait
+    for the garbage collector."""
     f = open(path, "rb")
     if f.read(len(MAGIC)) != MAGIC:
         f.close()

@@ -52,7 +52,9 @@ def _elevations(name: str) -> torch.Tensor:
     raise ValueError(name)
 
 
-def sensor_model(name: str, columns: int | None = None, device="cpu") -> SensorModel:
+def sensor_model(name: str, columns: int | None = None, device="cpu", az_offset: float = 0.0) -> SensorModel:
+    """`az_offset` (in columns) turns the start of the sweep: 0 starts half a column below +pi; 0.75 starts a quarter of a column beyond
+    the +-pi wrap of atan2, which is where startOri / endOri / halfPassed of src/scanRegistration.cpp:141-153,208-236 take their other arms."""
     spec = {
         "VLP-16": (16, 1800, 0.3, False, "firing"),
         "HDL-32": (32, 2048, 0.3, False, "firing"),
@@ -64,7 +66,7 @@ def sensor_model(name: str, columns: int | None = None, device="cpu") -> SensorM
         cols = columns
     el = torch.deg2rad(_elevations(name))
     k = torch.arange(cols, dtype=torch.float64)
-    az = math.pi - 2.0 * math.pi * (k + 0.5) / cols          # pi -> -pi, clockwise
+    az = math.pi - 2.0 * math.pi * (k + 0.5 - az_offset) / cols          # pi -> -pi, clockwise
     if order == "ring":
         el_g = el[:, None].expand(n_scans, cols)
         az_g = az[None, :].expand(n_scans, cols)
@@ -238,9 +240,10 @@ def render_scan(world: World, model: SensorModel, R: torch.Tensor, t: torch.Tens
 
 
 def make_sequence(model_name: str, n_frames: int, seed: int, noise_sigma: float | None = None, device="cpu",
-                  world_seed: int | None = None, step: float = 1.0, nan_fraction: float = 0.0, columns: int | None = None, rough: bool = False):
+                  world_seed: int | None = None, step: float = 1.0, nan_fraction: float = 0.0, columns: int | None = None, rough: bool = False,
+                  az_offset: float = 0.0):
     """Returns (scans: list of float32 [N_i,4] tensors, R [n,3,3], t [n,3], model)."""
-    model = sensor_model(model_name, columns=columns, device=device)
+    model = sensor_model(model_name, columns=columns, device=device, az_offset=az_offset)
     world = make_world(seed if world_seed is None else world_seed).to(device)
     if noise_sigma is None:
         noise_sigma = 0.01 if model_name == "VLP-16" else 0.02

@@ -77,7 +77,7 @@ typedef struct aloam_odom_stats {
   int lm_successful[2];
   double initial_cost[2];
   double final_cost[2];
-  int termination[2];      /* 0 max-iter, 1 parameter tol, 2 function tol, 3 gradient tol, 4 no residuals, 5 failure */
+  int termination[2];      /* 0 max-iter, 1 parameter tol, 2 function tol, 3 gradient tol, 4 no residuals, 5 failure, 6 minimum trust-region radius (Ceres: CONVERGENCE) */
 } aloam_odom_stats;
 
 /* ---- lifetime -------------------------------------------------------------------------------------------- */

@@ -102,7 +102,14 @@ enum DecisionKind { kDecCurvCorner = 0,   // cloudCurvature > 0.1      (referenc
                     kDecOdomNN = 4,       // pointSearchSqDis[0] < DISTANCE_SQ_THRESHOLD = 25 (reference src/laserOdometry.cpp:305,393)
                     kDecMapKnn = 5,       // pointSearchSqDis[4] < 1.0 (reference src/laserMapping.cpp:582,650)
                     kDecEigRatio = 6,     // saes.eigenvalues()[2] > 3 * saes.eigenvalues()[1] (:611)
-                    kDecPlaneFit = 7 };   // fabs(norm . p + negative_OA_dot_norm) > 0.2 (:672-681)
+                    kDecPlaneFit = 7,     // fabs(norm . p + negative_OA_dot_norm) > 0.2 (:672-681)
+                    // the decisions of ceres::Solve's trust-region loop that a different dense solve (Eigen's householderQr against this
+                    // repo's Householder / the device's Cholesky) could flip; value / threshold as compared (reference src/laserOdometry.cpp:494-499)
+                    kDecLmParamTol = 8,   // |x - x_candidate| <= parameter_tolerance (|x| + parameter_tolerance)
+                    kDecLmFuncTol = 9,    // |cost - cost_candidate| <= function_tolerance cost
+                    kDecLmAccept = 10,    // relative decrease > min_relative_decrease = 1e-3
+                    kDecLmGradTol = 11,   // gradient max-norm <= gradient_tolerance = 1e-10
+                    kDecLmModel = 12 };   // model_cost_change > 0 (step validity)
 struct Decision { int kind; double value, threshold; };
 extern thread_local std::vector<Decision>* g_decision_log;
 inline void log_decision(int kind, double value, double threshold) { if (g_decision_log) g_decision_log->push_back(Decision{kind, value, threshold}); }

@@ -319,7 +319,8 @@ for _name, _fn in _map_methods().items():
 
 
 DECISION_KINDS = ("curvature > 0.1", "curvature < 0.1", "gap^2 > 0.05", "range^2 < min_range^2", "odometry d2 < 25", "map 5th neighbour d2 < 1",
-                  "eigenvalue ratio > 3", "plane residual > 0.2")
+                  "eigenvalue ratio > 3", "plane residual > 0.2", "LM parameter tolerance", "LM function tolerance", "LM step acceptance (rel > 1e-3)",
+                  "LM gradient tolerance", "LM model change > 0")
 
 
 def decision_log(enable=True):

@@ -351,8 +351,12 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
   int iter = 0;
   while (true) {
     if (iter >= max_iterations) { sm.termination = 0; break; }
+    log_decision(kDecLmGradTol, gmax, kGradientTol);
     if (gmax <= kGradientTol) { sm.termination = 3; break; }
-    if (radius < kMinRadius) { sm.termination = 5; break; }
+    // Ceres 1.12 TrustRegionMinimizer::MinTrustRegionRadiusReached(): Radius() <= min_trust_region_radius ends the solve as CONVERGENCE
+    // ("Minimum trust region radius reached"), not as a failure.  Unreachable from 1e4 in the reference's 4 iterations (and in practice at
+    // all: a shrinking step meets the function tolerance first); kept literal.
+    if (radius <= kMinRadius) { sm.termination = 6; break; }
     ++iter;
     sm.iterations = iter;
     // -- LevenbergMarquardtStrategy::ComputeStep
@@ -379,6 +383,7 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
         model_change -= mi * (r[i] + mi / 2.0);
       }
     }
+    if (ok) log_decision(kDecLmModel, model_change, 0.0);
     if (!ok || !(model_change > 0.0)) {               // invalid step
       if (++n_invalid >= 5) { sm.termination = 5; break; }
       radius = radius / decrease_factor;
@@ -400,17 +405,24 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
     sn = std::sqrt(sn);
     const bool converged_param = sn <= kParameterTol * (x_norm + kParameterTol);
     const bool converged_func = std::fabs(cost - cost_c) <= kFunctionTol * cost;
+    log_decision(kDecLmParamTol, sn, kParameterTol * (x_norm + kParameterTol));
+    if (!converged_param) log_decision(kDecLmFuncTol, std::fabs(cost - cost_c), kFunctionTol * cost);
     if (converged_param || converged_func) {
       if (apply_converged_step && cost_c < cost) { for (int k = 0; k < 4; ++k) q[k] = qc[k]; for (int k = 0; k < 3; ++k) t[k] = tc[k]; cost = cost_c; }
       sm.termination = converged_param ? 1 : 2;
       break;
     }
     const double rel = (cost - cost_c) / model_change;
+    log_decision(kDecLmAccept, rel, kMinRelDecrease);
     if (rel > kMinRelDecrease) {                      // successful step
       for (int k = 0; k < 4; ++k) q[k] = qc[k];
       for (int k = 0; k < 3; ++k) t[k] = tc[k];
       update_x_norm();
       cost = pb.evaluate(q, t, &r, &J);
+      // HandleSuccessfulStep(): x is the candidate now; if residuals / Jacobian cannot be evaluated there the solve ends as FAILURE
+      bool jf = std::isfinite(cost);
+      for (double v : J) jf = jf && std::isfinite(v);
+      if (!jf) { sm.successful++; sm.termination = 5; break; }
       gmax = gradient_max(J, r);
       apply_scale(J);
       sm.successful++;

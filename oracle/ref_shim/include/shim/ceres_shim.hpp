@@ -196,7 +196,7 @@ struct Solver {
     double initial_cost = 0, final_cost = 0;
     int num_successful_steps = 0, num_unsuccessful_steps = 0, iterations = 0;
     TerminationType termination_type = NO_CONVERGENCE;
-    int shim_termination = 0;   // 0 max-iter, 1 parameter tol, 2 function tol, 3 gradient tol, 4 no residuals, 5 failure
+    int shim_termination = 0;   // 0 max-iter, 1 parameter tol, 2 function tol, 3 gradient tol, 4 no residuals, 5 failure, 6 minimum trust-region radius
     std::string message;
     std::string BriefReport() const { return message; }
     std::string FullReport() const { return message; }
@@ -358,7 +358,7 @@ inline void Solve(const Solver::Options& o, Problem* problem, Solver::Summary* s
   while (true) {
     if (iter >= o.max_num_iterations) { term = 0; break; }
     if (gmax <= o.gradient_tolerance) { term = 3; break; }
-    if (radius < o.min_trust_region_radius) { term = 5; break; }
+    if (radius <= o.min_trust_region_radius) { term = 6; break; }   // MinTrustRegionRadiusReached(): `<=`, CONVERGENCE
     ++iter;
     if (!reuse) for (int c = 0; c < n; ++c) { double s = 0.0; for (int i = 0; i < m; ++i) s += J[static_cast<size_t>(i) * n + c] * J[static_cast<size_t>(i) * n + c]; diag[c] = std::min(std::max(s, o.min_lm_diagonal), o.max_lm_diagonal); }
     reuse = true;
@@ -392,9 +392,14 @@ inline void Solve(const Solver::Options& o, Problem* problem, Solver::Summary* s
     if (rel > o.min_relative_decrease) {
       x = xc; x_norm = norm_of(x);
       ev.evaluate(x, &cost, &r, &J);
+      ++sum->num_successful_steps;
+      {   // HandleSuccessfulStep(): residuals / Jacobian must evaluate at the accepted point, else FAILURE
+        bool jf = std::isfinite(cost);
+        for (double v : J) jf = jf && std::isfinite(v);
+        if (!jf) { term = 5; break; }
+      }
       gmax = grad_max();
       scale_jac();
-      ++sum->num_successful_steps;
       const double c3 = 2.0 * rel - 1.0;
       radius = std::min(o.max_trust_region_radius, radius / std::max(1.0 / 3.0, 1.0 - c3 * c3 * c3));
       decrease = 2.0; reuse = false;

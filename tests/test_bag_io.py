@@ -63,6 +63,9 @@ def test_reader_rejects_what_it_cannot_read(tmp_path):
     p.write_bytes(good[:-40])                                               # cut inside the trailing index record
     with pytest.raises(rb.BagError, match="truncated"):
         list(rb.read_messages(str(p)))
+    p.write_bytes(b"#ROSBAG V2.0\n" + struct.pack("<I", 0xfffffff0) + b"garbage")   # a corrupt length word: refused before read() is asked for 4 GiB
+    with pytest.raises(rb.BagError, match="runs past the end"):
+        list(rb.read_messages(str(p)))
     lz4 = b"#ROSBAG V2.0\n" + _record((("op", b"\x05"), ("compression", b"lz4"), ("size", struct.pack("<I", 10))), b"0123456789")
     p.write_bytes(lz4)
     with pytest.raises(rb.BagError, match="lz4"):

@@ -79,3 +79,46 @@ def test_no_decision_sits_within_reach_of_a_last_bit_difference(O, sequence):
         for eps in (4 * 2.220446049250313e-16, 1e-12, PERTURBATION):
             for sgn in (-1.0, 1.0):
                 assert np.array_equal((v * (1.0 + sgn * eps)) > th, base), (O.DECISION_KINDS[kind], eps, sgn)
+
+
+# ---- the trust-region loop of ceres::Solve (reference src/laserOdometry.cpp:494-499, src/laserMapping.cpp:712-720) --------------------------------
+# Ceres solves the damped linear system with Eigen's householderQr; the oracle / the reference-TU build use this repo's Householder QR, the
+# device a Cholesky factorisation of the normal equations.  The step agrees to ~1e-15 relative, so the POSE is not in question; what a
+# different last bit could change is one of the loop's DECISIONS — parameter tolerance, function tolerance, step acceptance (relative
+# decrease > 1e-3), gradient tolerance, step validity (model change > 0).  Logged over the full-size reference fixtures' sweeps and
+# twenty-six fresh ones, with the margin of each.
+LM_KINDS = (8, 9, 10, 11)
+LM_MODEL_KIND = 12
+
+
+def test_lm_loop_decisions_sit_far_from_their_thresholds(O, sequence):
+    import json
+    O.decision_log(True)
+    sweeps = 0
+    runs = []
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "reffull_*.npz"))):
+        g = np.load(path)
+        runs.append((str(g["sensor"]), int(g["frames"]), dict(seed=int(g["seed"]), **json.loads(str(g["kwargs"])))))
+    runs += [("HDL-64", 6, dict(seed=51)), ("HDL-64", 6, dict(seed=52, rough=True)), ("VLP-16", 8, dict(seed=53)), ("HDL-32", 6, dict(seed=54, columns=1024))]
+    for name, frames, kw in runs:
+        scans, R, t, model = sequence(name, frames, **kw)
+        orc = O.Oracle(n_scans=model.n_scans, min_range=model.min_range)
+        for x in scans:
+            orc.scan_register(x)
+            orc.odometry_step()
+            sweeps += 1
+    kinds, values, thresholds = O.decisions()
+    O.decision_log(False)
+    assert sweeps >= 30
+    print(f"\nLM loop decisions over {sweeps} sweeps (two solves of <= 4 iterations each per sweep)")
+    for kind in LM_KINDS:
+        sel = kinds == kind
+        assert sel.sum() > 150, (O.DECISION_KINDS[kind], int(sel.sum()))
+        rel = np.abs(values[sel] - thresholds[sel]) / np.abs(thresholds[sel])
+        print(f"  {O.DECISION_KINDS[kind]:34s} n = {int(sel.sum()):5d}  closest relative margin {rel.min():.3g}  (value > threshold in {int((values[sel] > thresholds[sel]).sum())})")
+        # a dense solve that differs by 1e-12 relative (four orders above the observed 1e-15 .. 1e-16) cannot move any of them across
+        assert rel.min() > 1e-6, (O.DECISION_KINDS[kind], rel.min())
+    sel = kinds == LM_MODEL_KIND
+    assert sel.sum() > 150 and (values[sel] > 0).all()
+    print(f"  {O.DECISION_KINDS[LM_MODEL_KIND]:34s} n = {int(sel.sum()):5d}  smallest model change {values[sel].min():.3g} (threshold 0)")
+    assert values[sel].min() > 1e-9

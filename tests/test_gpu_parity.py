@@ -330,6 +330,48 @@ def test_last_clouds_that_are_not_ring_sorted_or_out_of_range(O, binding, sequen
     gpu.close()
 
 
+def test_flagged_sequences_among_normal_ones_in_one_batch(O, binding, sequence):
+    """k_associate_pair serves the sequences whose last clouds are ring-sorted and in range, k_associate_flagged (one workgroup per
+    sequence, returns at once otherwise) the others — in ONE launch pair per class.  A batch of five with two flagged sequences (one not
+    ring-sorted, one with far coordinates) between three normal ones: every sequence must give its own oracle's correspondences and pose."""
+    scans, R, t, model = sequence("HDL-64", 3, seed=8, columns=1024)
+    orc = O.Oracle(n_scans=64, min_range=model.min_range)
+    feats = []
+    for x in scans:
+        feats.append(orc.scan_register(x))
+        orc.odometry_step()
+    rng = np.random.default_rng(4)
+    base_c, base_s = feats[1]["less_sharp"], feats[1]["less_flat"]
+    lasts = []
+    for mode in ("normal", "unsorted", "normal", "far", "normal"):
+        c, sf = base_c.copy(), base_s.copy()
+        if mode == "unsorted":
+            c, sf = np.concatenate([c[len(c) // 2:], c[:len(c) // 2]]), np.concatenate([sf[len(sf) // 2:], sf[:len(sf) // 2]])
+        elif mode == "far":
+            sf[rng.integers(len(sf))][:3] = (5000.0, 10.0, 1.0)
+            c[rng.integers(len(c))][:3] = (-4200.0, 0.0, 0.0)
+        lasts.append((c, sf))
+    starts = [(np.array([0.0, 0.0, 0.01 * (b - 2), 1.0]), np.array([0.95 + 0.01 * b, 0.02, 0.0])) for b in range(5)]
+    gpu = _mk(binding, model, batch=5, max_points=70000)
+    oracles = []
+    for b, ((c, sf), (pq, pt)) in enumerate(zip(lasts, starts)):
+        pq = pq / np.linalg.norm(pq)
+        o2 = O.Oracle(n_scans=64, min_range=model.min_range)
+        o2.set_features(feats[2]); o2.set_last(c, sf); o2.set_state(pq, pt, [0, 0, 0, 1.0], [0, 0, 0.0], inited=True)
+        o2.odometry_step()
+        oracles.append(o2)
+        gpu.set_features(feats[2], seq=b); gpu.set_last(c, sf, seq=b); gpu.set_state(pq, pt, [0, 0, 0, 1.0], [0, 0, 0.0], seq=b, inited=True)
+    gpu.odometry_step()
+    for b, o2 in enumerate(oracles):
+        eo, plo, eqo, pqo = o2.correspondences()
+        eg, plg, eqg, pqg = gpu.correspondences(b)
+        assert np.array_equal(eqo, eqg) and np.array_equal(pqo, pqg), b
+        assert bits_equal(eo.astype(np.float32), eg) and bits_equal(plo.astype(np.float32), plg), b
+        _assert_pose_close(o2.pose(), gpu.pose(b), b)
+        assert min(o2.odom_stats()["plane_corr"]) > 100
+    gpu.close()
+
+
 @pytest.mark.parametrize("outer,lm", [(1, 4), (3, 2), (2, 8), (2, 0)])
 def test_solver_settings_other_than_the_reference_defaults(O, binding, sequence, outer, lm):
     """opti_counter loop (src/laserOdometry.cpp:278) and options.max_num_iterations (:496) are configuration here; the

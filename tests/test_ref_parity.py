@@ -87,7 +87,8 @@ def test_live_reference_build_matches_oracle(O, sequence):
         pytest.skip("reference sources not present on this box; the committed ref_*.npz fixtures cover it")
     assert ref_py.build()
     for name, frames, seed, kw in (("VLP-16", 3, 21, {"columns": 900}), ("HDL-32", 2, 22, {"columns": 500}), ("HDL-64", 3, 23, {"columns": 512}),
-                                   ("HDL-64", 3, 24, {"columns": 1024, "rough": True}), ("VLP-16", 3, 25, {"columns": 900, "rough": True})):   # rough: ragged rings, dropouts, curvature ties
+                                   ("HDL-64", 3, 24, {"columns": 1024, "rough": True}), ("VLP-16", 3, 25, {"columns": 900, "rough": True}),   # rough: ragged rings, dropouts, curvature ties
+                                   ("HDL-64", 2, 26, {}), ("HDL-32", 2, 27, {"columns": 1024}), ("HDL-64", 2, 28, {"az_offset": 0.75, "columns": 1024})):   # the benchmarked size, the 32-line formula at 1024 columns, a start beyond the +-pi wrap
         scans, R, t, model = sequence(name, frames, seed=seed, **kw)
         reg = ref_py.scan_registration(scans, model.n_scans, model.min_range)
         odo = ref_py.laser_odometry(reg)
@@ -228,6 +229,106 @@ def test_gpu_vs_reference_code(binding, path):
         last = (gpu.cloud(binding.CLOUD_CORNER_LAST), gpu.cloud(binding.CLOUD_SURF_LAST))
         gpu.odometry_step()
         if k > 0:   # closestPointInd / minPointInd2 / minPointInd3 of the reference's own run, index by index (each side looked up in its own clouds)
+            c = gpu.correspondences()
+            e, pl = _index_tables((c[0], c[1]), f, *last)
+            _assert_index_gap(e, g[f"edge_idx{k}"], (path, k, "edge")); _assert_index_gap(pl, g[f"plane_idx{k}"], (path, k, "plane"))
+            st = gpu.odom_stats()
+            assert abs(st["corner_corr"][1] - int(g[f"corr{k}"][0])) <= 1 and abs(st["plane_corr"][1] - int(g[f"corr{k}"][1])) <= 1, (path, k, st)
+        p = gpu.pose()
+        worst_t = max(worst_t, np.abs(p["t_lc"] - g[f"t_lc{k}"]).max(), np.linalg.norm(p["t_w"] - g[f"t_w{k}"]))
+        worst_r = max(worst_r, quat_angle(p["q_lc"], g[f"q_lc{k}"]), quat_angle(p["q_w"], g[f"q_w{k}"]))
+    assert worst_t < POSE_TOL_M and worst_r < POSE_TOL_RAD, (worst_t, worst_r)
+    gpu.close()
+
+
+# ---- the benchmarked size: 64 x 2048 sweeps (BASELINE.json configs[1]), KITTI-shaped irregular ones, the 32-line formula, a sweep that starts
+# beyond the +-pi wrap — outputs of the reference's own code (tests/golden/reffull_*.npz, tools/make_ref_golden.py --full).  The sweeps are
+# regenerated from the seed and checked against the stored sha256; big arrays are compared by the hash of the reference's bits.
+FULL_GOLDENS = sorted(glob.glob(os.path.join(GOLDEN, "reffull_*.npz")))
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _full_scans(g, sequence):
+    import json
+    scans, R, t, model = sequence(str(g["sensor"]), int(g["frames"]), seed=int(g["seed"]), **json.loads(str(g["kwargs"])))
+    for k, x in enumerate(scans):
+        assert len(x) == int(g[f"scan_n{k}"]) and _sha(x) == str(g[f"scan_sha{k}"]), "the synthetic generator no longer reproduces the sweeps the fixtures were made from"
+    return scans
+
+
+def test_full_goldens_present():
+    assert len(FULL_GOLDENS) >= 4, "tests/golden/reffull_*.npz missing: run tools/make_ref_golden.py --full where /root/reference exists"
+
+
+@pytest.mark.parametrize("path", FULL_GOLDENS)
+def test_oracle_vs_reference_code_at_benchmark_size(O, sequence, path):
+    """Literal order: every array the reference's own translation units produced, bit for bit (by value or by hash), poses to 1e-12, the index
+    tables of its factors identical.  Canonical order (= the HIP path): picks bit-exact, less-flat centroids <= 4 ulp, indices within the bound."""
+    g = np.load(path)
+    scans = _full_scans(g, sequence)
+    for canonical in (False, True):
+        orc = O.Oracle(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), canonical_order=canonical)
+        for k, x in enumerate(scans):
+            f = orc.scan_register(x)
+            for key in EXACT:
+                assert bits_equal(f[key], g[f"{key}{k}"]), (path, canonical, k, key)
+            assert _sha(f["cloud"]) == str(g[f"cloud_sha{k}"]), (path, canonical, k, "cloud")
+            lf = f["less_flat"]
+            assert len(lf) == int(g[f"less_flat_n{k}"]) and _sha(lf[:, 3].astype(np.int32)) == str(g[f"less_flat_int{k}"]), (path, canonical, k)
+            if k == 1:
+                assert _close_ulp(lf, g["less_flat1"]), (path, canonical)
+            last = (orc.cloud(O.CLOUD_CORNER_LAST), orc.cloud(O.CLOUD_SURF_LAST))
+            p = orc.odometry_step()
+            if not canonical:
+                assert _sha(lf) == str(g[f"less_flat_sha{k}"]), (path, k, "less_flat")
+                curv, lab, _ = orc.per_point()
+                n = int(g[f"cloud_n{k}"])
+                assert _sha(curv[:n]) == str(g[f"curvature_sha{k}"]) and _sha(lab[:n].astype(np.int32)) == str(g[f"label_sha{k}"]), (path, k)
+                for key in ("q_lc", "t_lc", "q_w", "t_w"):
+                    assert np.abs(p[key] - g[f"{key}{k}"]).max() < 1e-12, (path, k, key)
+                assert _sha(orc.cloud(O.CLOUD_CORNER_LAST)) == str(g[f"corner_last_sha{k}"]) and _sha(orc.cloud(O.CLOUD_SURF_LAST)) == str(g[f"surf_last_sha{k}"])
+            else:
+                assert np.abs(p["t_lc"] - g[f"t_lc{k}"]).max() < POSE_TOL_M and quat_angle(p["q_lc"], g[f"q_lc{k}"]) < POSE_TOL_RAD
+                assert np.linalg.norm(p["t_w"] - g[f"t_w{k}"]) < POSE_TOL_M and quat_angle(p["q_w"], g[f"q_w{k}"]) < POSE_TOL_RAD
+            if k == 0:
+                continue
+            e, pl = _index_tables(orc.correspondences(), f, *last)
+            if canonical:
+                _assert_index_gap(e, g[f"edge_idx{k}"], (path, k, "edge")); _assert_index_gap(pl, g[f"plane_idx{k}"], (path, k, "plane"))
+            else:
+                assert np.array_equal(e, g[f"edge_idx{k}"]) and np.array_equal(pl, g[f"plane_idx{k}"]), (path, k)
+                st = orc.odom_stats()
+                assert [st["corner_corr"][1], st["plane_corr"][1]] == list(g[f"corr{k}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FULL_GOLDENS)
+def test_gpu_vs_reference_code_at_benchmark_size(binding, sequence, path):
+    """The HIP path against the reference's own code on sweeps of the benchmarked size (131 072 points: the association's coarse shells, ring-grid
+    stages and 40 k-point last clouds), on KITTI-shaped irregular ones, through the 32-line ring formula and across the +-pi start: ring-ordered
+    cloud and picks bit-exact, less-flat centroids <= 4 ulp, the correspondence indices of every factor within the stated (measured: zero)
+    bound, poses within the north-star tolerance."""
+    g = np.load(path)
+    scans = _full_scans(g, sequence)
+    gpu = binding.Aloam(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), max_points=int(g["max_points"]) + 256)
+    worst_t = worst_r = 0.0
+    for k, x in enumerate(scans):
+        gpu.scan_register(x)
+        f = gpu.features()
+        for key in EXACT:
+            assert bits_equal(f[key], g[f"{key}{k}"]), (path, k, key)
+        assert _sha(f["cloud"]) == str(g[f"cloud_sha{k}"]), (path, k, "cloud")
+        lf = f["less_flat"]
+        assert len(lf) == int(g[f"less_flat_n{k}"]) and _sha(lf[:, 3].astype(np.int32)) == str(g[f"less_flat_int{k}"]), (path, k)
+        if k == 1:
+            assert _close_ulp(lf, g["less_flat1"]), path
+        last = (gpu.cloud(binding.CLOUD_CORNER_LAST), gpu.cloud(binding.CLOUD_SURF_LAST))
+        gpu.odometry_step()
+        if k > 0:
             c = gpu.correspondences()
             e, pl = _index_tables((c[0], c[1]), f, *last)
             _assert_index_gap(e, g[f"edge_idx{k}"], (path, k, "edge")); _assert_index_gap(pl, g[f"plane_idx{k}"], (path, k, "plane"))

@@ -132,8 +132,61 @@ def main_factors():
     print(path, os.path.getsize(path) // 1024, "KiB")
 
 
+# Sweeps of the BENCHMARKED size (BASELINE.json configs[1]: 64 x 2048) through the reference's own code, plus the three shapes the small
+# fixtures above do not hold: KITTI-shaped irregular sweeps at full size, the 32-line ring formula (src/scanRegistration.cpp:175-185), and
+# a sweep that starts just beyond the +-pi wrap of atan2 (:141-153,208-236).  The raw sweeps are NOT stored: a test regenerates them from
+# the seed (a-loam_amd/synthetic.py is deterministic on the CPU) and checks the sha256 stored here; of the big less-flat clouds only
+# frame 1 is stored (the <= 4 ulp comparison needs values), the other frames by hash of the reference's bits + size + integer intensities.
+FULL_CASES = [("reffull_hdl64_seed31", "HDL-64", 3, 31, {}),
+              ("reffull_hdl64_rough_seed32", "HDL-64", 3, 32, {"rough": True}),
+              ("reffull_hdl32_c1024_seed33", "HDL-32", 3, 33, {"columns": 1024}),
+              ("reffull_hdl64_wrap_seed34", "HDL-64", 3, 34, {"az_offset": 0.75})]
+
+
+def sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main_full():
+    import json
+    assert ref_py.build(), "oracle/_ref could not be built (is /root/reference present?)"
+    for tag, name, frames, seed, kw in FULL_CASES:
+        scans, R, t, model = syn.make_sequence(name, frames, seed=seed, **kw)
+        xs = [s.numpy() for s in scans]
+        reg = ref_py.scan_registration(xs, model.n_scans, model.min_range)
+        odo = ref_py.laser_odometry(reg)
+        out = {"sensor": name, "seed": seed, "kwargs": json.dumps(kw), "n_scans": model.n_scans, "min_range": model.min_range, "frames": frames,
+               "max_points": max(len(x) for x in xs)}
+        for k in range(frames):
+            out[f"scan_sha{k}"], out[f"scan_n{k}"] = sha(xs[k]), len(xs[k])
+            for key in ("sharp", "less_sharp", "flat"):
+                out[f"{key}{k}"] = reg[k][key]
+            lf = reg[k]["less_flat"]
+            out[f"less_flat_sha{k}"], out[f"less_flat_n{k}"] = sha(lf), len(lf)
+            out[f"less_flat_int{k}"] = sha(lf[:, 3].astype(np.int32))
+            if k == 1:
+                out[f"less_flat{k}"] = lf
+            n = len(reg[k]["curvature"])
+            out[f"cloud_n{k}"] = len(reg[k]["cloud"])
+            out[f"cloud_sha{k}"] = sha(reg[k]["cloud"])
+            out[f"curvature_sha{k}"], out[f"label_sha{k}"] = sha(reg[k]["curvature"][:n]), sha(reg[k]["label"][:n].astype(np.int32))
+            for key in ("q_lc", "t_lc", "q_w", "t_w"):
+                out[f"{key}{k}"] = odo[k][key]
+            out[f"corr{k}"] = np.array([odo[k]["corner_corr"], odo[k]["plane_corr"]])
+            out[f"corner_last_sha{k}"], out[f"surf_last_sha{k}"] = sha(odo[k]["corner_last"]), sha(odo[k]["surf_last"])
+            _store_indices(out, k, reg, odo)
+        path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path) // 1024, "KiB", [int(out[f"scan_n{k}"]) for k in range(frames)], [list(out[f"corr{k}"]) for k in range(frames)])
+
+
 if __name__ == "__main__":
-    main()
-    main_mapping()
-    main_factors()
-    main_distortion()
+    if "--full" in sys.argv:
+        main_full()
+    else:
+        main()
+        main_mapping()
+        main_factors()
+        main_distortion()
+        main_full()
