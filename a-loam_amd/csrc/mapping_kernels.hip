@@ -1248,6 +1248,9 @@ constexpr int kMapSearchThreads = ALOAM_MAP_SEARCH_THREADS;
 #ifndef ALOAM_MAP_TOP5_PACKED
 #define ALOAM_MAP_TOP5_PACKED 1    // A/B builds: 0 = the five neighbours with their coordinates in registers (rounds 2 - 4)
 #endif
+#ifndef ALOAM_MAP_SEARCH_TAIL_AT
+#define ALOAM_MAP_SEARCH_TAIL_AT k   // what a lane past the end of its bucket loads in a group of U: its own entry k (A/B builds: 0 = entry 0, one line for all such lanes)
+#endif
 #ifndef ALOAM_MAP_SEARCH_TAILS
 #define ALOAM_MAP_SEARCH_TAILS 0   // A/B builds: 1 = full groups of U, then the rest under exec masks (round 5: 84 - 92 registers instead of 50, 5.00 against 4.70 ms)
 #endif
@@ -1345,7 +1348,7 @@ __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int
         const int m = s1[c] - k;
         float4 p[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = sorted[u < m ? k + u : k];
+        for (int u = 0; u < U; ++u) p[u] = sorted[u < m ? k + u : ALOAM_MAP_SEARCH_TAIL_AT];
 #pragma unroll
         for (int u = 0; u < U; ++u) if (u < m) visit(p[u], k + u);
       }
@@ -1620,14 +1623,14 @@ __global__ __launch_bounds__(256) void k_map_fit(MapArgs a) {
         e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
 #pragma unroll
         for (int k = 0; k < 3; ++k) { e.a[k] = ra[k]; e.b[k] = rb[k]; }
-        e.valid = 1; e.pad = i;
+        e.pad = i;
         a.edges[(long long)b * a.R * 120 + i0 + rank] = e;
       } else {
         MapNormRec e;
         e.cp[0] = ori.x; e.cp[1] = ori.y; e.cp[2] = ori.z;
 #pragma unroll
         for (int k = 0; k < 3; ++k) e.n[k] = ra[k];
-        e.d = rd; e.valid = 1; e.pad = i;
+        e.d = rd; e.pad = i;
         a.norms[(long long)b * a.cap + i0 + rank] = e;
       }
     }

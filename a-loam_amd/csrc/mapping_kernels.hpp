@@ -33,8 +33,20 @@ struct alignas(16) MapSeq {                              // one per sequence
   int pad;
 };
 
-struct MapEdgeRec { double cp[3], a[3], b[3]; int valid, pad; };        // (pad: the stack index of the point)        // LidarEdgeFactor(curr_point, point_a, point_b, 1.0)      (:618)
-struct MapNormRec { double cp[3], n[3], d; int valid, pad; };          // LidarPlaneNormFactor(curr_point, norm, negative_OA_dot_norm) (:683)
+// Factor records of the valid stack points (k_map_fit -> k_map_solve; every LM evaluation streams them again, and k_map_solve runs at HBM
+// speed: bytes are its time).  curr_point is a float point of the stack, so it is kept as three floats (the same doubles come back when it
+// is read): 64 / 48 bytes instead of 80 / 64.  pad: the stack index of the point.
+#ifndef ALOAM_MAP_REC_F32CP
+#define ALOAM_MAP_REC_F32CP 1      // A/B builds: 0 = curr_point as three doubles + a `valid` word (rounds 2 - 4)
+#endif
+#if ALOAM_MAP_REC_F32CP
+struct MapEdgeRec { double a[3], b[3]; float cp[3]; int pad; };         // LidarEdgeFactor(curr_point, point_a, point_b, 1.0)      (:618)
+struct MapNormRec { double n[3], d; float cp[3]; int pad; };            // LidarPlaneNormFactor(curr_point, norm, negative_OA_dot_norm) (:683)
+static_assert(sizeof(MapEdgeRec) == 64 && sizeof(MapNormRec) == 48, "record sizes");
+#else
+struct MapEdgeRec { double cp[3], a[3], b[3]; int valid, pad; };
+struct MapNormRec { double cp[3], n[3], d; int valid, pad; };
+#endif
 
 struct VoxSeg {                                          // one pcl::VoxelGrid::filter call
   const float4* in;

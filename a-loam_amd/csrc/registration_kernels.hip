@@ -722,10 +722,15 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // ring-major over the batch, see voxel_runs_tail
 #if ALOAM_RF_TICKET
   // the ring of this workgroup = the next ticket of its sweep (see "output offsets across the rings of a sweep" above)
-  __shared__ int s_ticket;
-  if (tid == 0) s_ticket = __hip_atomic_fetch_add(a.ring_ticket + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_ticket[];
+  int* s_ticket = reinterpret_cast<int*>(smem_ticket);                       // first word of the dynamic LDS, free again after the barrier
+  typedef __attribute__((address_space(1))) int global_int;                 // a GLOBAL atomic (the generic pointer of the argument struct would make it a flat one)
+  if (tid == 0) *s_ticket = __hip_atomic_fetch_add((global_int*)(a.ring_ticket + b), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  const int r = __builtin_amdgcn_readfirstlane(s_ticket);
+  int r_ = __builtin_amdgcn_readfirstlane(*s_ticket);
+  asm volatile("" : "+s"(r_));                                               // a scalar register from here on, like blockIdx.y was
+  const int r = r_;
+  __syncthreads();
 #else
   const int r = blockIdx.y;
 #endif

@@ -81,6 +81,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120, help="timed steps of the headline leg (120 x ~9 ms: a timed region above one second); the other legs use min(steps, --extra-steps)")
     ap.add_argument("--extra-steps", type=int, default=30)
+    ap.add_argument("--repeat-to-seconds", type=float, default=1.0, help="after the K timed steps, time further identical K-step blocks until this many seconds are covered (0: off); reported as repeated_blocks, never as `value`")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="independent sequences per GPU (measured: 256 -> 77 k sweeps/s, 512 -> 86 k, 1024 -> 90 k, 2048 -> 93 k)")
     ap.add_argument("--frames", type=int, default=6, help="stored sweeps per sequence (replayed ping-pong)")
@@ -171,8 +172,11 @@ class Workload:
             "odometry + laserMapping scan-to-map refinement every sweep" if mapping else "odometry only (scan registration + scan-to-scan odometry, no laserMapping)")
 
 
-def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping):
-    """W untimed + exactly K timed steps with the inputs resident in HBM; per-kernel hipEvents on the context's own stream."""
+def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping, repeat_to_s=0.0, repeats_out=None):
+    """W untimed + exactly K timed steps with the inputs resident in HBM; per-kernel hipEvents on the context's own stream.
+    `repeat_to_s` > 0: after the K timed steps (which alone make `value`), further identical blocks of exactly K steps are timed the
+    same way (barrier + synchronize on both sides, MAX over ranks) until the blocks add up to that many seconds (at most 24 blocks), and
+    their times are appended to `repeats_out` — the driver's `--steps 20` times 0.2 s, too short to say anything about spread."""
     NC, BC = len(ctxs), wl.B // len(ctxs)
     order = frame_order(wl.T, warmup + steps)
     nin = {(k, c): wl.nin(k, c * BC, (c + 1) * BC) for k in range(wl.T) for c in range(NC)}
@@ -205,6 +209,25 @@ def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping):
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else wl.data.device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    snapshot = ctxs[0].profile() if NC == 1 else None      # the per-kernel profile is that of the K contract steps only
+    if repeat_to_s > 0 and repeats_out is not None and elapsed > 0:
+        cont = frame_order(wl.T, warmup + steps * 25)[warmup + steps:]          # the ping-pong replay simply goes on
+        for r in range(min(24, max(0, int(np.ceil(repeat_to_s / elapsed)) - 1))):   # the same count on every rank: `elapsed` is the MAX over ranks
+            if dist is not None:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for k in cont[r * steps:(r + 1) * steps]:
+                step(k)
+            for cx in ctxs:
+                cx.synchronize()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            if dist is not None:
+                dist.barrier()
+                tm = torch.tensor([el], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else wl.data.device)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                el = float(tm.item())
+            repeats_out.append(el)
     if NC > 1:                                             # per-kernel profile from one extra, untimed pass on a single context
         ctxs[0].profile_enable(True)
         for k in order[warmup:]:
@@ -212,7 +235,7 @@ def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping):
             if mapping:
                 ctxs[0].mapping_step()
         ctxs[0].synchronize()
-    prof = ctxs[0].profile()
+    prof = snapshot if snapshot is not None else ctxs[0].profile()
     ctxs[0].profile_enable(False)
     return elapsed, prof
 
@@ -558,7 +581,8 @@ def main():
     if args.mapping:
         for c in ctxs:
             c.mapping_enable(0.4, 0.8, args.map_pool)      # launch/aloam_velodyne_HDL_64.launch: mapping_line / plane_resolution
-    elapsed, prof = timed_resident(torch, dist, world, ctxs, wl, args.steps, args.warmup, args.mapping)
+    more = []
+    elapsed, prof = timed_resident(torch, dist, world, ctxs, wl, args.steps, args.warmup, args.mapping, repeat_to_s=args.repeat_to_seconds, repeats_out=more)
     bscan = survey_b_scan(ctxs[0], wl)
     free1, _ = torch.cuda.mem_get_info(dev)                # inputs + contexts of THIS rank (of every rank that shares the device under the test hook)
     try:
@@ -579,6 +603,12 @@ def main():
            "timed_region_s": round(elapsed, 3), "library_sha256": lib_sha256(),
            "memory": {"hbm_used_bytes": int(free0 - free1), "hbm_bytes_per_sequence": int((free0 - free1) / max(1, B)), "hbm_total_bytes": int(total_hbm),
                       "host_rss_bytes": rss, "host_ram_bytes": host_ram, "input_bytes": int(B * T * wl.NP * 16)}}
+    if more:     # spread of identical K-step blocks timed right after the contract block (which alone is `value` / `ms_per_step`)
+        blocks = [elapsed] + more
+        ms = sorted(1e3 * x / args.steps for x in blocks)
+        out["repeated_blocks"] = {"blocks": len(blocks), "steps_each": args.steps, "total_timed_s": round(sum(blocks), 3),
+                                  "ms_per_step": {"first": round(1e3 * elapsed / args.steps, 4), "median": round(float(np.median(ms)), 4), "min": round(ms[0], 4), "max": round(ms[-1], 4)},
+                                  "value_median": round(world * B * args.steps / (float(np.median(blocks))), 2)}
     # whole-path view with SURVEY.md 8(d)'s B_scan (one figure per sweep, measured sizes) next to the sum of the per-kernel floors above
     out["roofline"]["survey_b_scan"] = dict(bscan, achieved_gbs=round(value / world * bscan["bytes"] / 1e9, 2), frac=round(value / world * bscan["bytes"] / 1e9 / HBM_PEAK_GBS, 5),
                                             frac_of_measured_copy_peak=round(value / world * bscan["bytes"] / 6.29e12, 5))

@@ -48,9 +48,12 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 def test_ring_features_keeps_seven_workgroups_per_cu(registration):
     k = registration["k_ring_features<2048>"]
-    assert k[".vgpr_count"] <= 64 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
-    k = registration["k_ring_features<4096>"]                                  # the long-ring class: 38 KB of LDS, four workgroups per CU
-    assert k[".vgpr_count"] <= 80 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
+    # seven workgroups per CU = seven waves per SIMD: <= 72 registers.  (61 in round 4; the ring ticket's global atomic at the top of the
+    # kernel makes the compiler schedule for a lower occupancy target — 72 — whatever the ticket is used for; forcing 64 spills ten
+    # registers.  Seven against eight workgroups per CU was measured equal in round 4, and ticket against blockIdx.y in round 5.)
+    assert k[".vgpr_count"] <= 72 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
+    k = registration["k_ring_features<4096>"]                                  # the long-ring class: 38 KB of LDS, four workgroups per CU = four waves per SIMD
+    assert k[".vgpr_count"] <= 128 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
     for name in ("k_classify", "k_scatter", "k_find_ends", "k_ring_offsets"):
         k = registration[name]
         assert k[".vgpr_count"] <= 64 and k[".vgpr_spill_count"] == 0 and k[".sgpr_spill_count"] == 0, (name, k)
@@ -84,7 +87,7 @@ def test_solvers_hold_their_state_in_registers(odometry, mapping):
 def test_mapping_search_and_filters(mapping):
     for name in ("k_map_search<0>", "k_map_search<1>"):
         k = mapping[name]
-        assert k[".vgpr_count"] <= 80 and k[".vgpr_spill_count"] == 0, (name, k)
+        assert k[".vgpr_count"] <= 72 and k[".vgpr_spill_count"] == 0, (name, k)   # round 5: packed (distance, index) keys + positions: 63 / 65 registers, 7 - 8 waves per SIMD (72 / 74 before)
     # the LDS voxel filter keeps its keys in registers; the 1024-thread instance is capped at 128 VGPRs by its workgroup size and is
     # allowed the handful of spilled registers it has today, not more
     big = mapping["k_vox_lds<1024, 24576, 65536>"]
