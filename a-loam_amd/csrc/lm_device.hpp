@@ -222,8 +222,8 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
         cost = acc[27];
         ++successful;
         // HandleSuccessfulStep(): x is the candidate now; a Jacobian that cannot be evaluated there ends the solve as FAILURE.  (The sums
-        // are tested, not the entries: a finite entry beyond ~1e154 overflows in J^T J and reads as non-finite here, where Ceres, the
-        // oracle and the shim would go on — no real sweep comes within 150 orders of magnitude of that.)
+        // are tested, not the entries: a finite entry beyond ~1e154 overflows in J^T J and reads as non-finite here, where Ceres and
+        // the CPU restatements used by the tests would go on — no real sweep comes within 150 orders of magnitude of that.)
         if (!all_finite(acc, 28)) { termination = 5; break; }
         unpack(acc);
         gmax = gradient_max();
