@@ -81,7 +81,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=120, help="timed steps of the headline leg (120 x ~9 ms: a timed region above one second); the other legs use min(steps, --extra-steps)")
     ap.add_argument("--extra-steps", type=int, default=30)
-    ap.add_argument("--repeat-to-seconds", type=float, default=1.0, help="after the K timed steps, time further identical K-step blocks until this many seconds are covered (0: off); reported as repeated_blocks, never as `value`")
+    ap.add_argument("--repeat-to-seconds", type=float, default=1.0, help="after the K timed steps, time further identical K-step blocks until this many seconds are covered (0: off; always off with --no-extras); reported as repeated_blocks, never as `value`")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="independent sequences per GPU (measured: 256 -> 77 k sweeps/s, 512 -> 86 k, 1024 -> 90 k, 2048 -> 93 k)")
     ap.add_argument("--frames", type=int, default=6, help="stored sweeps per sequence (replayed ping-pong)")
@@ -582,7 +582,8 @@ def main():
         for c in ctxs:
             c.mapping_enable(0.4, 0.8, args.map_pool)      # launch/aloam_velodyne_HDL_64.launch: mapping_line / plane_resolution
     more = []
-    elapsed, prof = timed_resident(torch, dist, world, ctxs, wl, args.steps, args.warmup, args.mapping, repeat_to_s=args.repeat_to_seconds, repeats_out=more)
+    # (not under --no-extras: that is what the rocprofv3 / counter passes and the A/B scripts run, and they want exactly W + K steps)
+    elapsed, prof = timed_resident(torch, dist, world, ctxs, wl, args.steps, args.warmup, args.mapping, repeat_to_s=0.0 if args.no_extras else args.repeat_to_seconds, repeats_out=more)
     bscan = survey_b_scan(ctxs[0], wl)
     free1, _ = torch.cuda.mem_get_info(dev)                # inputs + contexts of THIS rank (of every rank that shares the device under the test hook)
     try:

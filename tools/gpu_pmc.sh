@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 $*"
+BENCH="python $R/bench.py --no-cpu-baseline --repeat-to-seconds 0 --steps 3 --warmup 1 $*"
 pass() {  # name, counters...
   local name=$1; shift
   rm -rf /tmp/pmc_$name
