@@ -948,6 +948,9 @@ __device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsign
   }
 }
 
+#ifndef ALOAM_ASSOC_DEBUG_LDS
+#define ALOAM_ASSOC_DEBUG_LDS 0     // occupancy experiments: dynamic LDS bytes per (single-wave) workgroup of k_associate_pair, used by nothing
+#endif                              // (round 5: 9 500 / 19 500 bytes = 4 / 2 waves per SIMD instead of 7: planar +38 % / +139 %, corner +48 % / +159 %)
 #ifndef ALOAM_PAIR_TAILS
 #define ALOAM_PAIR_TAILS 1           // A/B builds: 0 = the tails always one query at a time
 #endif
@@ -1492,11 +1495,11 @@ void launch_associate(const OdomArgs& a, bool plane, hipStream_t s) {
   if (ALOAM_ASSOC_PAIR == 2 || (ALOAM_ASSOC_PAIR == 1 && !plane)) {
     const dim3 grid((unsigned)(qcap / 2 * by)), block(64), gridf((unsigned)a.B), blockf(256);
     if (wide) {
-      if (plane) hipLaunchKernelGGL((k_associate_pair<true, true>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((k_associate_pair<false, true>), grid, block, 0, s, a);
+      if (plane) hipLaunchKernelGGL((k_associate_pair<true, true>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
+      else hipLaunchKernelGGL((k_associate_pair<false, true>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
     } else {
-      if (plane) hipLaunchKernelGGL((k_associate_pair<true, false>), grid, block, 0, s, a);
-      else hipLaunchKernelGGL((k_associate_pair<false, false>), grid, block, 0, s, a);
+      if (plane) hipLaunchKernelGGL((k_associate_pair<true, false>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
+      else hipLaunchKernelGGL((k_associate_pair<false, false>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
     }
     if (wide) {
       if (plane) hipLaunchKernelGGL((k_associate_flagged<true, false, true>), gridf, blockf, 0, s, a);

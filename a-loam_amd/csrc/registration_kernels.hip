@@ -1079,7 +1079,10 @@ void launch_classify(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_cla
 void launch_ring_offsets(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ring_offsets, dim3(a.B), dim3(1024), 0, s, a); }
 void launch_scatter(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_scatter, dim3(a.NB, a.B), dim3(256), 0, s, a); }
 void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s) {
-  const size_t lds = ring_features_lds_bytes(npad);
+#ifndef ALOAM_RF_DEBUG_LDS
+#define ALOAM_RF_DEBUG_LDS 0        // occupancy experiments: extra dynamic LDS bytes per ring workgroup, used by nothing
+#endif
+  const size_t lds = ring_features_lds_bytes(npad) + ALOAM_RF_DEBUG_LDS;
   if (npad <= 2048) hipLaunchKernelGGL(k_ring_features<2048>, dim3(a.B, a.R), dim3(256), lds, s, a, leaf);
   else hipLaunchKernelGGL(k_ring_features<4096>, dim3(a.B, a.R), dim3(256), lds, s, a, leaf);
   hipLaunchKernelGGL(k_cloud_sizes, dim3(a.B), dim3(64), 0, s, a);
