@@ -158,3 +158,56 @@ def test_final_place_offsets_from_published_ring_counts():
             assert np.all(g >> 32 == epoch) and not np.any(stale[cls, :r] >> 32 == epoch)
             out.append(int((g & 0xffffffff).sum()))
         assert out == list(np.concatenate([[0], np.cumsum(counts[cls])[:-1]]))
+
+
+# ======================================================================================================================
+# Round 5: which ring a k_ring_features workgroup works on.  Rounds 2 - 4 took it from blockIdx.y and were correct only while workgroups start
+# in linear order; now it is the next ticket of the sweep, taken when the workgroup starts executing (registration_kernels.hip, "output offsets
+# across the rings of a sweep").  A scheduler model: workgroups are STARTED in an arbitrary order onto a limited number of resident slots, a
+# resident workgroup publishes its count, then waits until all rings in front of it have published, then retires.  With tickets every order
+# terminates and every ring gets the offsets of the plain prefix sum; with blockIdx-derived rings an adversarial order fills all slots with
+# waiters and nothing ever retires (the bounded spin of the kernel would turn that into wrong offsets).
+# ======================================================================================================================
+def _run_rings(start_order, n_sweeps, n_rings, slots, counts, ticketed):
+    """-> (offsets[sweep][ring] or None on deadlock).  start_order: workgroup ids (sweep, y) in the order the dispatcher starts them."""
+    published = [[None] * n_rings for _ in range(n_sweeps)]
+    offsets = [[None] * n_rings for _ in range(n_sweeps)]
+    ticket = [0] * n_sweeps
+    pending, resident = list(start_order), []                                # resident: (sweep, ring) of running workgroups
+    while pending or resident:
+        progressed = False
+        while pending and len(resident) < slots:                             # the dispatcher fills free slots in ITS order
+            b, y = pending.pop(0)
+            r = ticket[b] if ticketed else y
+            ticket[b] += 1
+            published[b][r] = counts[b][r]                                   # selection done -> publish (never waits)
+            resident.append((b, r))
+            progressed = True
+        for wg in list(resident):                                            # gather: needs every ring in front of it
+            b, r = wg
+            if all(published[b][q] is not None for q in range(r)):
+                offsets[b][r] = sum(published[b][q] for q in range(r))
+                resident.remove(wg)
+                progressed = True
+        if not progressed:
+            return None                                                      # every slot holds a waiter and nothing can start: deadlock
+    return offsets
+
+
+def test_ring_tickets_make_the_lookback_independent_of_the_dispatch_order():
+    rng = np.random.default_rng(12)
+    n_sweeps, n_rings = 5, 16
+    counts = rng.integers(0, 40, (n_sweeps, n_rings)).tolist()
+    want = [[sum(counts[b][:r]) for r in range(n_rings)] for b in range(n_sweeps)]
+    ids = [(b, y) for y in range(n_rings) for b in range(n_sweeps)]          # the launch's linear order: ring-major over the sweeps
+    for slots in (1, 3, 7, 80):
+        for trial in range(40):
+            order = list(ids)
+            if trial:
+                rng.shuffle(order)
+            assert _run_rings(order, n_sweeps, n_rings, slots, counts, ticketed=True) == want, (slots, trial)
+        assert _run_rings(list(ids), n_sweeps, n_rings, slots, counts, ticketed=False) == want      # in-order dispatch: the old scheme worked
+    # the old scheme under an order HIP does not forbid: the last rings first, fewer slots than waiters
+    backwards = ids[::-1]
+    assert _run_rings(backwards, n_sweeps, n_rings, 7, counts, ticketed=False) is None
+    assert _run_rings(backwards, n_sweeps, n_rings, 7, counts, ticketed=True) == want
