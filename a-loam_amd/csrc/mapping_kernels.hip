@@ -1252,7 +1252,7 @@ constexpr int kMapSearchThreads = ALOAM_MAP_SEARCH_THREADS;
 #define ALOAM_MAP_SEARCH_TAIL_AT k   // what a lane past the end of its bucket loads in a group of U: its own entry k (A/B builds: 0 = entry 0, one line for all such lanes)
 #endif
 #ifndef ALOAM_MAP_SEARCH_TAILS
-#define ALOAM_MAP_SEARCH_TAILS 0   // A/B builds: 1 = full groups of U, then the rest under exec masks (round 5: 84 - 92 registers instead of 50, 5.00 against 4.70 ms)
+#define ALOAM_MAP_SEARCH_TAILS 0   // A/B builds: 1 = full groups of U, then the rest under exec masks (round 5: 84 - 92 registers instead of 72 - 74, 5.00 against 4.70 ms)
 #endif
 #ifndef ALOAM_MAP_SEARCH_NBLK0
 #define ALOAM_MAP_SEARCH_NBLK0 16  // workgroups per sequence, corner / surf class (A/B builds)
