@@ -7,7 +7,8 @@ tools/gpu_variants.sh; the full parity suite still decides what ships.
     # here (CPU, torch available): sweeps of a few distinct synthetic sequences -> tools/_ab_inputs.npz (git-ignored, travels with gpurun)
     python tools/ab_check.py make-inputs [--sensor HDL-64] [--frames 3] [--sequences 4]
     # on the GPU box, e.g.  gpurun --timeout 60 -- 'python tools/ab_check.py ab product a-loam_amd/lib/variants/libX.so'
-    python tools/ab_check.py run <lib | product> <out.npz> [--batch 1024] [--steps 12] [--mapping]
+    python tools/ab_check.py run <lib | product> <out.npz> [--batch 1024] [--steps 12] [--mapping] [--cube-hist]   # --cube-hist: sizes of the map cubes at the end
+    # ALOAM_AB_WATCHDOG=<seconds>: dump the Python stacks and exit if a run has not finished by then (the first process on a cold box can take a minute to page the HIP runtime in)
     python tools/ab_check.py compare <a.npz> <b.npz>
     python tools/ab_check.py ab <lib a> <lib b> [run options]        # run + run + compare, each run in its own process
 
@@ -149,6 +150,14 @@ def run(argv):
         for cls in (0, 1):
             q = max(1, st[cls * 32 + 1])
             print("corner" if cls == 0 else "plane", {names[i]: round(st[cls * 32 + i] / q, 3) for i in sorted(names)}, "queries", st[cls * 32 + 1])
+    if mapping and "--cube-hist" in argv:                        # sizes of the map cubes the per-cube re-filter works on (k_vox_lds instances: <= 2048 / <= 8192 / <= 65536 points)
+        L.aloam_map_cube_counts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        for b in watch:
+            for cls in (0, 1):
+                cnt = np.zeros(21 * 21 * 11, np.int32)
+                L.aloam_map_cube_counts(gpu.h, b, cls, cnt.ctypes.data)
+                nz = np.sort(cnt[cnt > 0])[::-1]
+                print(f"seq {b} {'corner' if cls == 0 else 'surf'}: {len(nz)} cubes, {int(nz.sum())} points; sizes", nz.tolist())
     gpu.close()
     hip.free(base)
     print(lib_path, "->", out_path, "kernel ms per step:", round(sum(v["total_ms"] for v in prof.values()) / steps, 3))
@@ -184,5 +193,8 @@ def ab(argv):
 
 
 if __name__ == "__main__":
+    if os.environ.get("ALOAM_AB_WATCHDOG"):                      # seconds: dump every thread's Python stack and exit if the run has not finished by then
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["ALOAM_AB_WATCHDOG"]), exit=True)
     cmd, args = sys.argv[1], sys.argv[2:]
     sys.exit({"make-inputs": make_inputs, "run": run, "compare": compare, "ab": ab}[cmd](args) or 0)
