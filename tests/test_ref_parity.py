@@ -396,6 +396,71 @@ def test_mapping_oracle_canonical_order_vs_reference_code(O, path):
             assert sum(1 for c in want if len(want[c]) != len(got[c])) <= MAP_POINTS_PER_FRAME_BOUND, (path, k, name)
 
 
+# ---- the whole chain at the benchmarked size: registration -> odometry -> mapping by the reference's three translation units on 64 x 2048 sweeps
+# (tests/golden/reffullmap_*.npz, tools/make_ref_golden.py --full-mapping; the sweeps are regenerated from the seed, the cube map is compared by
+# the sha256 of the reference's bits for the literal order and by occupancy / population for the canonical order and the HIP path).
+FULL_MAP_GOLDENS = sorted(glob.glob(os.path.join(GOLDEN, "reffullmap_*.npz")))
+
+
+def _check_map_against_golden(g, k, pose, cubes_of, ctx, literal):
+    """pose: refined pose dict of frame k; cubes_of(cls) -> {cube: points}."""
+    if literal:
+        for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+            assert np.abs(pose[key] - g[f"{key}{k}"]).max() < 1e-12, (ctx, k, key)
+    else:
+        assert np.abs(pose["t_w"] - g[f"t_w{k}"]).max() < POSE_TOL_M and quat_angle(pose["q_w"], g[f"q_w{k}"]) < POSE_TOL_RAD, (ctx, k)
+    for cls, name in ((0, "corner_map"), (1, "surf_map")):
+        got = cubes_of(cls)
+        ids, cnt = [int(i) for i in g[f"{name}_ids{k}"]], [int(c) for c in g[f"{name}_cnt{k}"]]
+        assert sorted(got) == ids, (ctx, k, name, sorted(set(got) ^ set(ids)))
+        if literal:
+            assert [len(got[c]) for c in ids] == cnt and _sha(np.concatenate([got[c] for c in ids])) == str(g[f"{name}_sha{k}"]), (ctx, k, name)
+        else:
+            assert abs(sum(cnt) - sum(len(v) for v in got.values())) <= MAP_POINTS_PER_FRAME_BOUND, (ctx, k, name, sum(cnt), sum(len(v) for v in got.values()))
+            assert sum(1 for c, n in zip(ids, cnt) if len(got[c]) != n) <= MAP_POINTS_PER_FRAME_BOUND, (ctx, k, name)
+
+
+@pytest.mark.parametrize("path", FULL_MAP_GOLDENS)
+def test_oracle_full_chain_vs_reference_code_at_benchmark_size(O, sequence, path):
+    g = np.load(path)
+    scans = _full_scans(g, sequence)
+    for canonical in (False, True):
+        orc = O.Oracle(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), canonical_order=canonical)
+        orc.map_config(float(g["line_res"]), float(g["plane_res"]))
+        for k, x in enumerate(scans):
+            orc.scan_register(x)
+            po = orc.odometry_step()
+            if not canonical:
+                assert np.abs(po["q_w"] - g[f"odom_q{k}"]).max() < 1e-12 and np.abs(po["t_w"] - g[f"odom_t{k}"]).max() < 1e-12
+            pm = orc.mapping_step(po["q_w"], po["t_w"], orc.cloud(O.CLOUD_CORNER_LAST), orc.cloud(O.CLOUD_SURF_LAST), orc.cloud(O.CLOUD_FULL))
+            _check_map_against_golden(g, k, pm, orc.map_cubes, (path, canonical), literal=not canonical)
+            if not canonical:
+                reg = orc.map_cloud(O.MAP_REGISTERED)
+                assert len(reg) == int(g[f"registered_n{k}"]) and _sha(reg) == str(g[f"registered_sha{k}"]), (path, k)
+                info = orc.map_info()
+                assert (info["cenW"], info["cenH"], info["cenD"]) == tuple(int(v) for v in g[f"cen{k}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", FULL_MAP_GOLDENS)
+def test_gpu_full_chain_vs_reference_code_at_benchmark_size(binding, sequence, path):
+    """Registration + odometry + scan-to-map refinement on the device, 64 x 2048 sweeps, against the reference's own three translation units run
+    end to end: the same cubes occupied after every frame, populations within the stated bound, refined poses within 1e-4 m / rad."""
+    g = np.load(path)
+    scans = _full_scans(g, sequence)
+    gpu = binding.Aloam(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), max_points=int(g["max_points"]) + 256)
+    gpu.mapping_enable(float(g["line_res"]), float(g["plane_res"]), pool_points=131072)
+    for k, x in enumerate(scans):
+        gpu.scan_register(x)
+        gpu.odometry_step()
+        gpu.mapping_step()
+        gpu.synchronize()
+        _check_map_against_golden(g, k, gpu.map_pose(), gpu.map_cubes, path, literal=False)
+        info = gpu.map_info()
+        assert (info["cenW"], info["cenH"], info["cenD"]) == tuple(int(v) for v in g[f"cen{k}"])
+    gpu.close()
+
+
 def test_mapping_population_gap_of_the_canonical_order(O, sequence):
     """The same question for the cube map (laserMapping.cpp:737-801): canonical order (HIP path) against literal order (= the reference's code,
     pinned bit for bit above) through registration + odometry + mapping on fresh sweeps: same cubes, every population within one point, at most

@@ -181,12 +181,50 @@ def main_full():
         print(path, os.path.getsize(path) // 1024, "KiB", [int(out[f"scan_n{k}"]) for k in range(frames)], [list(out[f"corr{k}"]) for k in range(frames)])
 
 
+# The whole chain registration -> odometry -> mapping by the reference's three translation units on sweeps of the benchmarked size: refined poses,
+# map<-odom transforms, cube window and the cube map (ids, populations, sha256 of every class's points in cube order) after every frame.
+FULL_MAP_CASES = [("reffullmap_hdl64_seed41", "HDL-64", 4, 41, {}, 0.4, 0.8)]
+
+
+def main_full_mapping():
+    import json
+    assert ref_py.build()
+    for tag, name, frames, seed, kw, line_res, plane_res in FULL_MAP_CASES:
+        scans, R, t, model = syn.make_sequence(name, frames, seed=seed, **kw)
+        xs = [s.numpy() for s in scans]
+        reg = ref_py.scan_registration(xs, model.n_scans, model.min_range)
+        odo = ref_py.laser_odometry(reg)
+        fr = [dict(q_w=o["q_w"], t_w=o["t_w"], corner_last=o["corner_last"], surf_last=o["surf_last"], cloud=r["cloud"]) for o, r in zip(odo, reg)]
+        mp = ref_py.laser_mapping(fr, line_res, plane_res)
+        out = {"sensor": name, "seed": seed, "kwargs": json.dumps(kw), "n_scans": model.n_scans, "min_range": model.min_range, "frames": frames,
+               "max_points": max(len(x) for x in xs), "line_res": line_res, "plane_res": plane_res}
+        for k in range(frames):
+            out[f"scan_sha{k}"], out[f"scan_n{k}"] = sha(xs[k]), len(xs[k])
+            out[f"odom_q{k}"], out[f"odom_t{k}"] = fr[k]["q_w"], fr[k]["t_w"]
+            for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+                out[f"{key}{k}"] = mp[k][key]
+            out[f"cen{k}"] = np.array(mp[k]["cen"])
+            out[f"registered_sha{k}"], out[f"registered_n{k}"] = sha(mp[k]["registered"]), len(mp[k]["registered"])
+            for nm in ("corner_map", "surf_map"):
+                ids = sorted(mp[k][nm])
+                out[f"{nm}_ids{k}"] = np.array(ids, np.int32)
+                out[f"{nm}_cnt{k}"] = np.array([len(mp[k][nm][c]) for c in ids], np.int32)
+                out[f"{nm}_sha{k}"] = sha(np.concatenate([mp[k][nm][c] for c in ids]) if ids else np.zeros((0, 4), np.float32))
+        path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path) // 1024, "KiB", [int(out[f"corner_map_cnt{k}"].sum()) for k in range(frames)], [int(out[f"surf_map_cnt{k}"].sum()) for k in range(frames)])
+
+
 if __name__ == "__main__":
-    if "--full" in sys.argv:
+    if "--full-mapping" in sys.argv:
+        main_full_mapping()
+    elif "--full" in sys.argv:
         main_full()
+        main_full_mapping()
     else:
         main()
         main_mapping()
         main_factors()
         main_distortion()
         main_full()
+        main_full_mapping()
