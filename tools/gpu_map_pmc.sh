@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   lib=product; [ "$v" != product ] && lib=$R/a-loam_amd/lib/variants/lib$v.so
   rm -rf /tmp/pm_$v
-  timeout 300 rocprofv3 --pmc $CNT --kernel-trace --kernel-include-regex "${KREGEX:-map_search}" --output-format csv -d /tmp/pm_$v -o p -- python $R/tools/ab_check.py run $lib /tmp/pm_$v.npz --mapping --steps ${AB_STEPS:-4} > $O/pmc_$v.log 2>&1
+  timeout 300 rocprofv3 --pmc $CNT --kernel-trace --kernel-include-regex "${KREGEX:-map_search}" --output-format csv -d /tmp/pm_$v -o p -- python $R/tools/ab_check.py run $lib /tmp/pm_$v.npz ${AB_MAPPING---mapping} --steps ${AB_STEPS:-4} > $O/pmc_$v.log 2>&1
   python - <<PY | tee -a $O/pmc_summary.txt
 import glob, pandas as pd
 cc = pd.concat([pd.read_csv(f) for f in glob.glob("/tmp/pm_$v/**/*counter_collection.csv", recursive=True)])
