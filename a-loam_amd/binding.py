@@ -108,6 +108,10 @@ def lib():
         L.aloam_get_correspondences.argtypes = [vp, C.c_int, vp, C.c_int, ip, vp, vp, C.c_int, ip, vp]
         L.aloam_mapping_enable.argtypes = [vp, C.c_float, C.c_float, C.c_int]
         L.aloam_mapping_step.argtypes = [vp]
+        L.aloam_mapping_set_pool_limit.argtypes = [vp, C.c_int]
+        L.aloam_get_map_pool_info.argtypes = [vp, vp]
+        L.aloam_set_map.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]
+        L.aloam_set_map_frame.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
         L.aloam_set_full_cloud.argtypes = [vp, C.c_int, vp, C.c_int]
         L.aloam_get_map_pose.argtypes = [vp, C.c_int, vp, vp, vp, vp]
         L.aloam_get_map_info.argtypes = [vp, C.c_int, vp]
@@ -270,8 +274,27 @@ class Aloam:
         return e[:ne.value].copy(), p[:npl.value].copy(), eq[:ne.value].copy(), pq[:npl.value].copy()
 
     # ---- stage 3 -------------------------------------------------------------------------------------------
-    def mapping_enable(self, line_res=0.4, plane_res=0.8, pool_points=262144):
+    def mapping_enable(self, line_res=0.4, plane_res=0.8, pool_points=262144, pool_limit=None):
+        """pool_points: where the map pools start (they double as the map grows); pool_limit: the ceiling (None = the library's default)."""
+        if pool_limit is not None:
+            self._check(lib().aloam_mapping_set_pool_limit(self.h, int(pool_limit)))
         self._check(lib().aloam_mapping_enable(self.h, float(line_res), float(plane_res), int(pool_points)))
+
+    def map_pool_info(self):
+        v = np.zeros(4, np.int32)
+        self._check(lib().aloam_get_map_pool_info(self.h, _p(v)))
+        return {"pool_points": int(v[0]), "growths": int(v[1]), "limit": int(v[2]), "live_max": int(v[3])}
+
+    def set_map(self, cubes, cls, seq=0):
+        """cubes: {cube index: (n, 4) points} -> laserCloudCornerArray (cls 0) / laserCloudSurfArray (cls 1) of the sequence."""
+        ids = np.array(sorted(cubes), np.int32)
+        cnt = np.array([len(cubes[int(i)]) for i in ids], np.int32)
+        pts = _f32(np.concatenate([cubes[int(i)] for i in ids])) if len(ids) else np.zeros((0, 4), np.float32)
+        self._check(lib().aloam_set_map(self.h, seq, cls, _p(ids), _p(cnt), len(ids), _p(pts)))
+
+    def set_map_frame(self, cen, q_wmap_wodom, t_wmap_wodom, frame_count, seq=0):
+        a, q, t = np.ascontiguousarray(cen, dtype=np.int32), _f64(q_wmap_wodom), _f64(t_wmap_wodom)
+        self._check(lib().aloam_set_map_frame(self.h, seq, _p(a), _p(q), _p(t), int(frame_count)))
 
     def mapping_step(self):
         self._check(lib().aloam_mapping_step(self.h))

@@ -72,12 +72,21 @@ struct aloam_ctx {
   long long map_err_reported = 0;    // voxel-scratch capacity events (vox counters[3]) aloam_synchronize has already returned
   std::vector<long long> map_err_seen;   // per sequence: pool capacity events (MapSeq.err_steps) already returned
   float map_line_res = 0.4f, map_plane_res = 0.8f;
-  int map_pool = 0, map_H[2] = {0, 0}, map_levels = 0, map_cube_levels = 0, map_tile_cap = 0, map_tile_bound[2] = {0, 0}, map_nsegs_max = 0;
+  int map_pool = 0, map_H = 0, map_levels = 0, map_cube_levels = 0, map_tile_cap = 0, map_tile_bound[2] = {0, 0}, map_nsegs_max = 0;
   long long map_key_cap = 0;
+  // pool growth (map_ensure_capacity): the reference's cubes are std::vectors that grow without bound (src/laserMapping.cpp:737-783)
+  int map_pool_limit = 1 << 26;      // ceiling per sequence and class (aloam_mapping_set_pool_limit); ALOAM_E_CAPACITY only there
+  int map_growths = 0;
+  long long map_steps = 0;           // mapping steps queued so far
+  int nin_max = 0;                   // largest scan handed to the last registration call (bounds what one step can add to a map)
+  volatile int* h_map_report = nullptr;   // pinned: {step, live corner, live surf, stack corner, stack surf} of the last finished step
+  int* d_map_report_host = nullptr;       // the same memory as the device sees it
+  int* d_map_report = nullptr; int* d_map_live = nullptr;
+  hipEvent_t map_step_done[4] = {};
   MapSeq* d_mapseq = nullptr; CubeDesc* d_cubes = nullptr; float4* d_pool[2] = {nullptr, nullptr}; int* d_maptab = nullptr;
   float4* d_stack[2] = {nullptr, nullptr}; float4* d_stack_world[2] = {nullptr, nullptr}; int* d_stack_cube[2] = {nullptr, nullptr};
   int *d_addcnt = nullptr, *d_cursor = nullptr, *d_compact_flag = nullptr;
-  float4* d_mgrid_sorted[2] = {nullptr, nullptr}; int* d_mgrid_start[2] = {nullptr, nullptr}; int* d_mgrid_cnt[2] = {nullptr, nullptr};
+  float4* d_mgrid_sorted[2] = {nullptr, nullptr}; int* d_mgrid_start[2] = {nullptr, nullptr};
   MapEdgeRec* d_medges = nullptr; MapNormRec* d_mnorms = nullptr; float4* d_registered = nullptr; float4* d_knn = nullptr;
   int* d_vox_lists = nullptr;
   int* d_rec_tiles = nullptr; int rec_tiles_corner = 0, rec_tiles_per_seq = 0;
@@ -215,10 +224,13 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   if (!(c->stages & ALOAM_STAGE_REGISTRATION)) { c->err = "this context was created without ALOAM_STAGE_REGISTRATION"; return ALOAM_E_STATE; }
   if (stride_bytes < 12 || (stride_bytes & 3)) { c->err = "stride_bytes must be 12 (x, y, z only) or >= 16, and a multiple of 4"; return ALOAM_E_ARG; }
   if (stride_bytes == 12 && c->cfg.ring_from_field) { c->err = "ring_from_field needs the 4th float of every record: stride_bytes >= 16"; return ALOAM_E_ARG; }
+  int nin_max = 0;
   for (int b = 0; b < c->B; ++b) {
     if (n_in[b] < 0) { c->err = "negative point count"; return ALOAM_E_ARG; }
     if (n_in[b] > c->cap) { c->err = "scan exceeds max_points"; return ALOAM_E_CAPACITY; }
+    nin_max = std::max(nin_max, n_in[b]);
   }
+  c->nin_max = nin_max;
   const int ns = c->h_nin_slot;
   c->h_nin_slot = (ns + 1) % kNinSlots;
   int* nin_slot = c->h_nin + (size_t)ns * c->B;
@@ -367,11 +379,13 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_grid_start3c[0], c->d_grid_start3c[1],
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
-                  c->d_mgrid_start[1], c->d_mgrid_cnt[0], c->d_mgrid_cnt[1], c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
+                  c->d_mgrid_start[1], c->d_map_report, c->d_map_live, c->d_medges, c->d_mnorms, c->d_registered, c->d_segs, c->d_tile_seg,
                   c->d_tile_heads, c->d_tile_pref, c->d_vox_counters, c->d_bbox, c->d_keys[0], c->d_keys[1], c->d_voxtmp, c->d_knn, c->d_compact_flag, c->d_vox_lists, c->d_rec_tiles};
   for (void* p : bufs) if (p) (void)hipFree(p);
   if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_nin) (void)hipHostFree(c->h_nin);
+  if (c->h_map_report) (void)hipHostFree((void*)c->h_map_report);
+  for (hipEvent_t e : c->map_step_done) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : c->nin_done) if (e) (void)hipEventDestroy(e);
   for (int k = 0; k < 2; ++k) { if (c->in_copied[k]) (void)hipEventDestroy(c->in_copied[k]); if (c->in_consumed[k]) (void)hipEventDestroy(c->in_consumed[k]); }
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -836,7 +850,7 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
         switch (kernel) {
           case K_MAP_BEGIN: bytes += 2.0 * kMapValidMax * sizeof(CubeDesc) + sizeof(MapSeq); break;           // window descriptors + state
           case K_MAP_VOXEL_STACK: bytes += 16 * (Lcl + Lsl) + 16 * (Sc + Ss); break;                          // incoming clouds in, stacks out
-          case K_MAP_GRID: bytes += 32 * (Mc + Ms) + 8.0 * (c->map_H[0] + c->map_H[1]); break;               // submap in, bucketed copy + tables out
+          case K_MAP_GRID: bytes += 32 * (Mc + Ms) + 16.0 * c->map_H; break;               // submap in, bucketed copy + tables out
           case K_MAP_ASSOC: bytes += 16 * (Sc + Ss) + 80 * (Sc + Ss) + sizeof(MapEdgeRec) * Sc + sizeof(MapNormRec) * Ss; break;   // query + 5 neighbours in, record out
           case K_MAP_SOLVE: bytes += 9.0 * (sizeof(MapEdgeRec) * Fc + sizeof(MapNormRec) * Fs); break;        // <= 5 Jacobian + 4 cost evaluations
           case K_MAP_INSERT: bytes += 32 * (Sc + Ss); break;                                                  // stacks in, cube appends out
@@ -864,8 +878,9 @@ static MapArgs map_args(aloam_ctx* c) {
   a.cubes = c->d_cubes; a.pool_cap = c->map_pool; a.tab = c->d_maptab;
   for (int k = 0; k < 2; ++k) {
     a.pool[k] = c->d_pool[k]; a.stack[k] = c->d_stack[k]; a.stack_world[k] = c->d_stack_world[k]; a.stack_cube[k] = c->d_stack_cube[k];
-    a.grid_sorted[k] = c->d_mgrid_sorted[k]; a.grid_start[k] = c->d_mgrid_start[k]; a.grid_cnt[k] = c->d_mgrid_cnt[k]; a.grid_H[k] = c->map_H[k];
+    a.grid_sorted[k] = c->d_mgrid_sorted[k]; a.grid_start[k] = c->d_mgrid_start[k];
   }
+  a.grid_H = c->map_H; a.live = c->d_map_live; a.report_dev = c->d_map_report; a.report_host = c->d_map_report_host;
   a.addcnt = c->d_addcnt; a.cursor = c->d_cursor; a.compact_flag = c->d_compact_flag;
   a.edges = c->d_medges; a.norms = c->d_mnorms; a.knn = c->d_knn;
   a.lm_max_iterations = c->cfg.lm_max_iterations;
@@ -881,6 +896,88 @@ static VoxArgs vox_args(aloam_ctx* c, int n_segs, int levels) {
   return v;
 }
 
+// Everything whose size follows the pool: the two class pools (contents kept when growing), the bucketed copy of the submap, the scratch of
+// the general voxel path (keys, staging = 2 pools per sequence, tile lists) and the bucket tables.  New buffers are allocated first and
+// the old ones released only when every allocation has succeeded, so a failed growth leaves the context as it was.
+static int map_alloc_pool(aloam_ctx* c, int pool_points) {
+  const size_t B = c->B, cap = c->cap, R = c->R, T = kVoxTile, pool = pool_points, old_pool = c->map_pool;
+  int H = 4096;
+  while (H < (int)(pool / 16) && H < kMapGridMaxH) H <<= 1;            // ~ submap size
+  const long long key_cap = (long long)(B * std::max(cap + R * 120, 2 * pool));
+  const int tile_bound1 = (int)(B * (2 * pool / T + 2 * kMapValidMax));
+  const int tile_cap = std::max(c->map_tile_bound[0], tile_bound1);
+  float4 *n_pool[2] = {nullptr, nullptr}, *n_sorted[2] = {nullptr, nullptr}, *n_tmp = nullptr;
+  int *n_start[2] = {nullptr, nullptr}, *n_tseg = nullptr, *n_theads = nullptr, *n_tpref = nullptr;
+  unsigned long long* n_keys[2] = {nullptr, nullptr};
+  bool ok = true;
+  auto grab = [&](void** p, size_t bytes) { if (ok && hipMalloc(p, bytes) != hipSuccess) { *p = nullptr; ok = false; (void)hipGetLastError(); } };
+  for (int k = 0; k < 2; ++k) {
+    grab((void**)&n_pool[k], sizeof(float4) * B * pool);
+    grab((void**)&n_sorted[k], sizeof(float4) * B * pool);
+    grab((void**)&n_start[k], sizeof(int) * B * ((size_t)H + 1));
+    grab((void**)&n_keys[k], sizeof(unsigned long long) * (size_t)key_cap);
+  }
+  grab((void**)&n_tmp, sizeof(float4) * (size_t)key_cap);
+  grab((void**)&n_tseg, sizeof(int) * (size_t)tile_cap);
+  grab((void**)&n_theads, sizeof(int) * (size_t)tile_cap);
+  grab((void**)&n_tpref, sizeof(int) * ((size_t)tile_cap + 1));
+  if (ok && prepare_map_grid(H)) ok = false;
+  if (!ok) {
+    void* fresh[] = {n_pool[0], n_pool[1], n_sorted[0], n_sorted[1], n_start[0], n_start[1], n_keys[0], n_keys[1], n_tmp, n_tseg, n_theads, n_tpref};
+    for (void* q : fresh) if (q) (void)hipFree(q);
+    c->err = "map pool of " + std::to_string(pool_points) + " points per sequence and class: allocation failed";
+    return ALOAM_E_HIP;
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (old_pool) HIP_TRY(c, hipMemcpy2DAsync(n_pool[k], sizeof(float4) * pool, c->d_pool[k], sizeof(float4) * old_pool, sizeof(float4) * old_pool, B, hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(c, hipMemsetAsync(n_pool[k], 0, sizeof(float4) * B * pool, c->stream));
+    HIP_TRY(c, hipMemsetAsync(n_start[k], 0, sizeof(int) * B * ((size_t)H + 1), c->stream));
+  }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  void* old[] = {c->d_pool[0], c->d_pool[1], c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0], c->d_mgrid_start[1], c->d_keys[0], c->d_keys[1],
+                 c->d_voxtmp, c->d_tile_seg, c->d_tile_heads, c->d_tile_pref};
+  for (void* q : old) if (q) (void)hipFree(q);
+  for (int k = 0; k < 2; ++k) { c->d_pool[k] = n_pool[k]; c->d_mgrid_sorted[k] = n_sorted[k]; c->d_mgrid_start[k] = n_start[k]; c->d_keys[k] = n_keys[k]; }
+  c->d_voxtmp = n_tmp; c->d_tile_seg = n_tseg; c->d_tile_heads = n_theads; c->d_tile_pref = n_tpref;
+  c->map_pool = pool_points; c->map_H = H; c->map_key_cap = key_cap; c->map_tile_bound[1] = tile_bound1; c->map_tile_cap = tile_cap;
+  c->map_cube_levels = 0;                                  // one 50 m cube may hold up to the whole pool: enough merge levels for that
+  while (((size_t)kVoxTile << c->map_cube_levels) < pool) ++c->map_cube_levels;   // (levels a cube does not need cost one skipped tile loop each)
+  return ALOAM_OK;
+}
+
+// The reference's cubes are std::vectors: a map grows as long as the sensor travels (src/laserMapping.cpp:737-783).  Here a (sequence,
+// class) pool must hold the live points of its cubes plus what the step adds, and the steps are queued asynchronously, so the host sizes
+// the pools AHEAD of the device from what k_map_report wrote after the last step that has finished: live points + (steps in flight + 1) x
+// the most a step can add.  "The most": the stack sizes of the step are not known before its voxel filter has run, so it is the scan size
+// (a stack is a filtered subset of one sweep) until a step has reported, then twice the largest stack any step has produced so far - a
+// step that breaks that bound AND fills the pool drops points and raises ALOAM_E_CAPACITY like a full pool at the ceiling does.  When the
+// bound exceeds the pool: wait for the device (the report is then exact), double the pool until it holds the bound, move the contents.
+static int map_ensure_capacity(aloam_ctx* c) {
+  if (c->map_pool >= c->map_pool_limit) return ALOAM_OK;     // at the ceiling: nothing to decide (the device counts what does not fit)
+  const int hard[2] = {std::min(c->R * 120, c->nin_max ? c->nin_max : c->cap), std::min(c->cap, c->nin_max ? c->nin_max : c->cap)};
+  auto bound = [&](long long lag) {
+    const int done = c->h_map_report[0];
+    long long worst = 0;
+    for (int k = 0; k < 2; ++k) {
+      const int inc = done > 0 ? std::min(hard[k], 2 * (int)c->h_map_report[3 + k] + 1024) : hard[k];
+      worst = std::max(worst, (long long)c->h_map_report[1 + k] + (lag + 1) * inc);
+    }
+    return worst;
+  };
+  const long long lag = c->map_steps - c->h_map_report[0];
+  if (bound(lag) <= c->map_pool) return ALOAM_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));               // now the report is that of the last queued step
+  const long long need = bound(std::min<long long>(lag, 3));   // keep room for the run-ahead this caller has shown
+  if (need <= c->map_pool || c->map_pool >= c->map_pool_limit) return ALOAM_OK;
+  long long np = c->map_pool;
+  while (np < need) np *= 2;
+  np = std::min<long long>(np, c->map_pool_limit);
+  const int rc = map_alloc_pool(c, (int)np);
+  if (rc) { c->map_pool_limit = c->map_pool; return ALOAM_OK; }   // out of device memory: this pool is the ceiling from now on
+  c->map_growths += 1;
+  return ALOAM_OK;
+}
+
 int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool_points) {
   DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
@@ -889,36 +986,32 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   if (!(line_res > 0.f) || !(plane_res > 0.f) || pool_points < 4096 || pool_points > (1 << 26)) { c->err = "bad mapping parameters (4096 <= pool_points <= 2^26)"; return ALOAM_E_ARG; }
   const size_t B = c->B, cap = c->cap, R = c->R;
   c->map_line_res = line_res; c->map_plane_res = plane_res;
-  c->map_pool = (pool_points + 1023) / 1024 * 1024;
-  const size_t pool = c->map_pool;
-  for (int k = 0; k < 2; ++k) { int H = 4096; while (H < (int)pool / 16 && H < (1 << 17)) H <<= 1; c->map_H[k] = H; }   // ~ submap size, not pool size
   c->map_levels = 0;                                       // incoming clouds: up to max_points
   while (((size_t)kVoxTile << c->map_levels) < cap) ++c->map_levels;
-  c->map_cube_levels = 0;                                  // one 50 m cube may hold up to the whole pool: enough merge levels for that
-  while (((size_t)kVoxTile << c->map_cube_levels) < pool) ++c->map_cube_levels;   // (levels a cube does not need cost one skipped tile loop each)
   const size_t T = kVoxTile;
   c->map_tile_bound[0] = (int)(B * ((cap + T - 1) / T + (R * 120 + T - 1) / T));
-  c->map_tile_bound[1] = (int)(B * (2 * pool / T + 2 * kMapValidMax));
-  c->map_tile_cap = std::max(c->map_tile_bound[0], c->map_tile_bound[1]);
-  c->map_key_cap = (long long)(B * std::max(cap + R * 120, 2 * pool));
   c->map_nsegs_max = (int)(B * 2 * kMapValidMax);
   int rc = 0;
+  const int pool0 = (pool_points + 1023) / 1024 * 1024;
+  if (c->map_pool_limit < pool0) c->map_pool_limit = pool0;
+  if ((rc = map_alloc_pool(c, pool0))) return rc;
   if ((rc = dmalloc(c, &c->d_mapseq, B))) return rc;
   if ((rc = dmalloc(c, &c->d_cubes, B * 2 * kMapCubes))) return rc;
   if ((rc = dmalloc(c, &c->d_maptab, B * kTabInts))) return rc;
   if ((rc = dmalloc(c, &c->d_addcnt, B * 2 * kMapCubes))) return rc;
   if ((rc = dmalloc(c, &c->d_cursor, B * 2 * kMapCubes))) return rc;
   if ((rc = dmalloc(c, &c->d_compact_flag, B * 2))) return rc;
+  if ((rc = dmalloc(c, &c->d_map_live, B * 2))) return rc;
+  if ((rc = dmalloc(c, &c->d_map_report, 4))) return rc;
+  HIP_TRY(c, hipHostMalloc((void**)&c->h_map_report, sizeof(int) * 8, hipHostMallocMapped));
+  for (int k = 0; k < 8; ++k) c->h_map_report[k] = 0;
+  HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_map_report_host, (void*)c->h_map_report, 0));
+  for (hipEvent_t& e : c->map_step_done) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (int k = 0; k < 2; ++k) {
     const size_t per = k == 0 ? R * 120 : cap;
-    if ((rc = dmalloc(c, &c->d_pool[k], B * pool))) return rc;
     if ((rc = dmalloc(c, &c->d_stack[k], B * per))) return rc;
     if ((rc = dmalloc(c, &c->d_stack_world[k], B * per))) return rc;
     if ((rc = dmalloc(c, &c->d_stack_cube[k], B * per))) return rc;
-    if ((rc = dmalloc(c, &c->d_mgrid_sorted[k], B * pool))) return rc;
-    if ((rc = dmalloc(c, &c->d_mgrid_start[k], B * ((size_t)c->map_H[k] + 1)))) return rc;
-    if ((rc = dmalloc(c, &c->d_mgrid_cnt[k], B * (size_t)c->map_H[k]))) return rc;
-    if ((rc = dmalloc(c, &c->d_keys[k], (size_t)c->map_key_cap))) return rc;
   }
   c->rec_tiles_corner = (int)((R * 120 + 255) / 256);
   c->rec_tiles_per_seq = c->rec_tiles_corner + (int)((cap + 255) / 256);
@@ -928,15 +1021,10 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   if ((rc = dmalloc(c, &c->d_registered, B * cap))) return rc;
   if ((rc = dmalloc(c, &c->d_knn, B * cap * 4))) return rc;
   if ((rc = dmalloc(c, &c->d_segs, (size_t)c->map_nsegs_max))) return rc;
-  if ((rc = dmalloc(c, &c->d_tile_seg, (size_t)c->map_tile_cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_tile_heads, (size_t)c->map_tile_cap))) return rc;
-  if ((rc = dmalloc(c, &c->d_tile_pref, (size_t)c->map_tile_cap + 1))) return rc;
   if ((rc = dmalloc(c, &c->d_vox_counters, 8))) return rc;
   if ((rc = dmalloc(c, &c->d_vox_lists, 3 * (size_t)c->map_nsegs_max))) return rc;
   if (prepare_voxel_filter()) { c->err = "k_vox_lds: dynamic LDS size rejected"; return ALOAM_E_HIP; }
-  if (prepare_map_grid(c->map_H[0])) { c->err = "k_mapgrid_build: dynamic LDS size rejected"; return ALOAM_E_HIP; }
   if ((rc = dmalloc(c, &c->d_bbox, (size_t)c->map_nsegs_max * 6))) return rc;
-  if ((rc = dmalloc(c, &c->d_voxtmp, (size_t)c->map_key_cap))) return rc;
   std::vector<MapSeq> init(B);
   std::memset(init.data(), 0, sizeof(MapSeq) * B);
   for (size_t b = 0; b < B; ++b) {                       // reference src/laserMapping.cpp:72-74,109,115
@@ -949,10 +1037,32 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   return ALOAM_OK;
 }
 
+int aloam_mapping_set_pool_limit(aloam_ctx* c, int max_pool_points) {
+  if (!c) return ALOAM_E_ARG;
+  if (max_pool_points < 4096 || max_pool_points > (1 << 26)) { c->err = "bad pool limit (4096 .. 2^26 points)"; return ALOAM_E_ARG; }
+  c->map_pool_limit = std::max((max_pool_points + 1023) / 1024 * 1024, c->map_pool);
+  return ALOAM_OK;
+}
+
+int aloam_get_map_pool_info(aloam_ctx* c, int out[4]) {
+  DeviceScope device_scope(c);
+  if (!c || !out) return ALOAM_E_ARG;
+  if (!c->map_on) { c->err = "mapping not enabled"; return ALOAM_E_STATE; }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out[0] = c->map_pool; out[1] = c->map_growths; out[2] = c->map_pool_limit;
+  out[3] = std::max((int)c->h_map_report[1], (int)c->h_map_report[2]);
+  return ALOAM_OK;
+}
+
 int aloam_mapping_step(aloam_ctx* c) {
   DeviceScope device_scope(c);
   if (!c) return ALOAM_E_ARG;
   if (!c->map_on) { c->err = "aloam_mapping_step before aloam_mapping_enable"; return ALOAM_E_STATE; }
+  // at most four steps queued ahead of the device: the occupancy report the pools are sized from is never older than that
+  hipEvent_t done = c->map_step_done[c->map_steps & 3];
+  if (c->map_steps >= 4) HIP_TRY(c, hipEventSynchronize(done));
+  int rc = map_ensure_capacity(c);
+  if (rc) return rc;
   const MapArgs a = map_args(c);
   { ProfScope p(c, K_MAP_BEGIN); launch_map_begin(a, c->stream); }
   { ProfScope p(c, K_MAP_VOXEL_STACK);                                      // downSizeFilterCorner / Surf on the incoming clouds (:542-550)
@@ -971,7 +1081,10 @@ int aloam_mapping_step(aloam_ctx* c) {
     HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 4 * sizeof(int), c->stream));
     launch_map_cube_segments(a, v, c->stream);
     launch_voxel_filter(v, c->map_tile_bound[1], c->stream); }
-  { ProfScope p(c, K_MAP_REGISTER); launch_map_register(a, c->stream); }    // :836-846
+  { ProfScope p(c, K_MAP_REGISTER); launch_map_register(a, c->stream);      // :836-846
+    c->map_steps += 1;
+    launch_map_report(a, (int)c->map_steps, c->stream); }
+  HIP_TRY(c, hipEventRecord(done, c->stream));
   HIP_TRY(c, hipGetLastError());
   return ALOAM_OK;
 }
@@ -987,6 +1100,56 @@ int aloam_set_full_cloud(aloam_ctx* c, int seq, const float* cloud, int n) {
   HIP_TRY(c, hipMemcpy(&m, c->d_meta + seq, sizeof(SeqMeta), hipMemcpyDeviceToHost));
   m.n_cloud = n;
   HIP_TRY(c, hipMemcpy(c->d_meta + seq, &m, sizeof(SeqMeta), hipMemcpyHostToDevice));
+  return ALOAM_OK;
+}
+
+// The mapping node's globals for one sequence (reference src/laserMapping.cpp:72-74,84-91,115-116): what a test or a restarted node
+// injects to continue from a known map.
+int aloam_set_map(aloam_ctx* c, int seq, int cls, const int* cube_ids, const int* counts, int n_cubes, const float* points_xyzw) {
+  DeviceScope device_scope(c);
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if (!c->map_on) { c->err = "mapping not enabled"; return ALOAM_E_STATE; }
+  if (cls < 0 || cls > 1 || n_cubes < 0 || (n_cubes && (!cube_ids || !counts))) { c->err = "bad class / cube list"; return ALOAM_E_ARG; }
+  long long total = 0;
+  std::vector<CubeDesc> d(kMapCubes, CubeDesc{0, 0, 0, 0});
+  for (int i = 0; i < n_cubes; ++i) {
+    if (cube_ids[i] < 0 || cube_ids[i] >= kMapCubes || counts[i] < 0 || d[cube_ids[i]].cap) { c->err = "bad or repeated cube index"; return ALOAM_E_ARG; }
+    d[cube_ids[i]] = CubeDesc{(int)total, counts[i], counts[i], 0};
+    total += counts[i];
+  }
+  if (total && !points_xyzw) return ALOAM_E_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (total > c->map_pool) {
+    long long np = c->map_pool;
+    while (np < total) np *= 2;
+    if (np > c->map_pool_limit) { c->err = "the injected map exceeds the pool limit"; return ALOAM_E_CAPACITY; }
+    if ((rc = map_alloc_pool(c, (int)np))) return rc;
+    c->map_growths += 1;
+  }
+  HIP_TRY(c, hipMemcpy(c->d_cubes + ((size_t)seq * 2 + cls) * kMapCubes, d.data(), sizeof(CubeDesc) * kMapCubes, hipMemcpyHostToDevice));
+  if (total) HIP_TRY(c, hipMemcpy(c->d_pool[cls] + (size_t)seq * c->map_pool, points_xyzw, sizeof(float4) * (size_t)total, hipMemcpyHostToDevice));
+  MapSeq ms;
+  HIP_TRY(c, hipMemcpy(&ms, c->d_mapseq + seq, sizeof(MapSeq), hipMemcpyDeviceToHost));
+  ms.pool_used[cls] = (int)total;
+  HIP_TRY(c, hipMemcpy(c->d_mapseq + seq, &ms, sizeof(MapSeq), hipMemcpyHostToDevice));
+  c->h_map_report[1 + cls] = std::max((int)c->h_map_report[1 + cls], (int)total);   // the pools are sized from this until the next step reports
+  return ALOAM_OK;
+}
+
+int aloam_set_map_frame(aloam_ctx* c, int seq, const int cen[3], const double q_wmap_wodom[4], const double t_wmap_wodom[3], int frame_count) {
+  DeviceScope device_scope(c);
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if (!c->map_on) { c->err = "mapping not enabled"; return ALOAM_E_STATE; }
+  if (!cen || !q_wmap_wodom || !t_wmap_wodom) return ALOAM_E_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  MapSeq ms;
+  HIP_TRY(c, hipMemcpy(&ms, c->d_mapseq + seq, sizeof(MapSeq), hipMemcpyDeviceToHost));
+  for (int k = 0; k < 3; ++k) { ms.cen[k] = cen[k]; ms.t_wmap_wodom[k] = t_wmap_wodom[k]; }
+  for (int k = 0; k < 4; ++k) ms.q_wmap_wodom[k] = q_wmap_wodom[k];
+  ms.frame_count = frame_count;
+  HIP_TRY(c, hipMemcpy(c->d_mapseq + seq, &ms, sizeof(MapSeq), hipMemcpyHostToDevice));
   return ALOAM_OK;
 }
 

@@ -9,8 +9,7 @@
 //   k_vox_lds          pcl::VoxelGrid::filter (:542-550 incoming clouds, :788-801 per-cube re-filter) of one segment by one workgroup:
 //                      run heads -> (voxel, first point) keys -> stable radix sort in registers / LDS -> centroids in input order
 //   k_vox_*            the same through global memory for segments that do not fit (tile sort + rank-merge levels)
-//   k_mapgrid_build    pcl::KdTreeFLANN::setInputCloud (:558-559): 2 m cell hash over the submap, LDS counting sort per (sequence,
-//                      class); k_mapgrid_count/scan/fill: the global-atomic form for tables that do not fit the LDS
+//   k_mapgrid_build    pcl::KdTreeFLANN::setInputCloud (:558-559): 2 m cell hash over the submap, LDS counting sort per (sequence, class)
 //   k_map_search/_fit  :576-706  pointAssociateToMap, nearestKSearch(k = 5) as an exact fixed-radius search (the reference
 //                      only uses the result when the 5th neighbour is closer than 1 m), line fit (3x3 symmetric
 //                      eigen-decomposition) / plane fit (5x3 least squares), valid factor records compacted per tile of 256 points
@@ -38,10 +37,8 @@ __device__ __forceinline__ unsigned hash_cell(int a, int b, int c) {
 // eight cells of any 2x2x2 block land in eight DIFFERENT buckets (k_map_search walks them without a duplicate test), and the cells of
 // one super-cell are neighbours in the bucket table and therefore in the sorted copy of the submap: the 64 queries of a wave, close
 // together in space, read close together in memory.
-#ifndef ALOAM_MAP_BUCKET_BITS
-#define ALOAM_MAP_BUCKET_BITS 1
-#endif
-constexpr int kMapLocalBits = ALOAM_MAP_BUCKET_BITS;
+constexpr int kMapLocalBits = 1;
+static_assert(kMapLocalBits >= 1 && kMapLocalBits <= 4, "k_map_search walks the eight cells of a 2x2x2 block without a duplicate test: they must land in eight different buckets");
 __device__ __forceinline__ unsigned map_local_bits(int v, int axis) {      // bit i of v -> bit 3 i + axis
   unsigned l = 0;
 #pragma unroll
@@ -641,7 +638,7 @@ __global__ __launch_bounds__(256) void k_vox_copyback(VoxArgs v) {
 //           "canonical order" of DESIGN.md section 5); centroid = sums / count
 // A segment whose runs do not fit (kVox*Runs), whose coordinates exceed the range where floor(p * inv) is an exact f32 integer
 // below 2^23, or that is larger than the list limits falls through to the general path untouched (counters[4]).
-// Measured per 40 k-point segment (1024 threads, device timers of a -DALOAM_VOX_TIMING build): pass 1 36 us, pass 2 30, sort 70 (a
+// Measured per 40 k-point segment (1024 threads, device timers of an instrumented round-3 build): pass 1 36 us, pass 2 30, sort 70 (a
 // bitonic network on the same pairs: 385), heads 3, sums 190 before / ~70 after the batched loads.
 // Stable LSD radix sort of n (voxel index, first point) pairs by the voxel index, 7 bits per pass.  The runs were generated in
 // input order, so a STABLE sort on the voxel index alone leaves the runs of one voxel in ascending point order — the order the
@@ -722,11 +719,6 @@ __device__ __forceinline__ void radix_sort_pairs(unsigned* hi, unsigned short* l
   }
 }
 
-#ifdef ALOAM_VOX_TIMING   // variant builds (tools/build_variant.sh): block 0 prints the time of every phase of its first segment
-#define VOX_T(name) do { __syncthreads(); if (blockIdx.x == 0 && tid == 0 && li == blockIdx.x) { const long long t_ = wall_clock64(); printf("k_vox_lds %d n %d phase %d : %d x10ns\n", NT, n, __LINE__, (int)(t_ - t_prev)); t_prev = t_; } } while (0)
-#else
-#define VOX_T(name) do { } while (0)
-#endif
 template <int NT, int CAPR, int CAPN>
 __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
   constexpr int NW = NT / 64, ITS = CAPR / NT, U = 4;
@@ -752,9 +744,6 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
     const float inv = 1.0f / sg.leaf;
     const int chunk = ((n + NW - 1) / NW + 63) & ~63;                        // every wave owns a contiguous, 64-aligned stretch of the segment
     const int w0 = wave * chunk, w1 = min(n, w0 + chunk);
-#ifdef ALOAM_VOX_TIMING
-    long long t_prev = wall_clock64();
-#endif
     // ---- pass 1: bounding box, run heads ------------------------------------------------------------------------------------
     float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
     int heads = 0;
@@ -804,7 +793,6 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
 #pragma unroll 1
       for (int w = 1; w < NW; ++w) { gmn[q] = fminf(gmn[q], s_f[q * NW + w]); gmx[q] = fmaxf(gmx[q], s_f[(3 + q) * NW + w]); }
     }
-    VOX_T("pass1");
     int n_runs = 0, rank = 0;
     bool unfit = false;
 #pragma unroll 1
@@ -850,13 +838,11 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
         }
       }
       __syncthreads();
-      VOX_T("pass2");
       {
         const long long cells = (long long)divb[0] * divb[1] * divb[2];      // every voxel index is below this (<= 2^31 - 1)
         const int key_bits = cells > 1 ? 64 - __clzll(cells - 1) : 1;
         radix_sort_pairs<NT, CAPR>(khi, klo, cntw, s_i + 32, n_runs, key_bits, tid);
       }
-      VOX_T("sort");
       // ---- voxel heads among the sorted runs -> output rank ---------------------------------------------------------------------
       const int rounds = (n_runs + NT - 1) / NT;                             // rounds of NT sorted runs that hold any
       for (int it = 0; it < rounds; ++it) {
@@ -880,7 +866,6 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
       }
       __syncthreads();
       n_vox = s_tab[ITS * NW];
-      VOX_T("heads");
       // ---- centroids: the members of a voxel in input order (runs ascending, points of a run consecutive) ----------------------
 #pragma unroll 1
       for (int it = 0; it < rounds; ++it) {
@@ -918,10 +903,6 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
         stage[s_tab[it * NW + wave] + vrank] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
       }
     }
-    VOX_T("sums");
-#ifdef ALOAM_VOX_TIMING
-    if (blockIdx.x == 0 && tid == 0 && li == blockIdx.x) printf("k_vox_lds<%d> n %d runs %d voxels %d\n", NT, n, n_runs, n_vox);
-#endif
     if (sg.final_out) {                                                      // in-place filter: back over the cube once every member has been read
       __syncthreads();
       if (stage != sg.final_out && !(dx * dy * dz > 2147483647ll)) for (int i = tid; i < n_vox; i += NT) sg.final_out[i] = stage[i];
@@ -935,65 +916,15 @@ __global__ __launch_bounds__(NT) void k_vox_lds(VoxArgs v, int which) {
 }
 
 // =======================================================================================================
-// kd-tree stand-in over the submap: 1 m cell hash, global counting sort
+// kd-tree stand-in over the submap: 2 m cell hash (map_bucket)
 // =======================================================================================================
-__global__ __launch_bounds__(256) void k_mapgrid_count(MapArgs a) {
-  const int b = blockIdx.y, cls = blockIdx.z;
-  const MapSeq& ms = a.seq[b];
-  const int n = ms.from_total[cls];
-  const int* tab = a.tab + (long long)b * kTabInts;
-  const int H = a.grid_H[cls];
-  int* cnt = a.grid_cnt[cls] + (long long)b * H;
-  for (int g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
-    const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
-    atomicAdd(&cnt[map_bucket((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv), H)], 1);
-  }
-}
-
-__global__ __launch_bounds__(1024) void k_mapgrid_scan(MapArgs a) {
-  const int b = blockIdx.x, cls = blockIdx.y, tid = threadIdx.x;
-  const int H = a.grid_H[cls];
-  int* cnt = a.grid_cnt[cls] + (long long)b * H;
-  int* start = a.grid_start[cls] + (long long)b * (H + 1);
-  __shared__ int part[1024];
-  const int per = H / 1024;
-  int local = 0;
-  for (int k = 0; k < per; ++k) local += cnt[tid * per + k];
-  part[tid] = local;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const int x = tid >= d ? part[tid - d] : 0;
-    __syncthreads();
-    part[tid] += x;
-    __syncthreads();
-  }
-  int run = part[tid] - local;
-  for (int k = 0; k < per; ++k) { const int c = cnt[tid * per + k]; start[tid * per + k] = run; cnt[tid * per + k] = run; run += c; }
-  if (tid == 1023) start[H] = run;
-}
-
-__global__ __launch_bounds__(256) void k_mapgrid_fill(MapArgs a) {
-  const int b = blockIdx.y, cls = blockIdx.z;
-  const MapSeq& ms = a.seq[b];
-  const int n = ms.from_total[cls];
-  const int* tab = a.tab + (long long)b * kTabInts;
-  const int H = a.grid_H[cls];
-  int* cur = a.grid_cnt[cls] + (long long)b * H;
-  float4* sorted = a.grid_sorted[cls] + (long long)b * a.pool_cap;
-  for (int g = blockIdx.x * 256 + threadIdx.x; g < n; g += gridDim.x * 256) {
-    const float4 p = submap_point(a, b, cls, tab, ms.n_valid, g);
-    const int pos = atomicAdd(&cur[map_bucket((int)floorf(p.x * kMapCellInv), (int)floorf(p.y * kMapCellInv), (int)floorf(p.z * kMapCellInv), H)], 1);
-    sorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(g));
-  }
-}
-
-// The same structure built by ONE 1024-thread workgroup per (sequence, class) with an LDS counting sort (count -> scan -> fill),
-// the way k_build_grids builds the odometry grids: no global atomics, no zero-fill of the count table, one launch instead of
-// memset + three.  Used whenever the bucket table fits the LDS (H <= 16384, i.e. pools up to 256 k points per class).
+// Built by ONE 1024-thread workgroup per (sequence, class) with an LDS counting sort (count -> scan -> fill), the way k_build_grids
+// builds the odometry grids: no global atomics, no zero-fill of a count table, one launch.  32-bit counters, so the submap may be of
+// any size; the bucket table is capped at 32768 entries (132 KiB of the CU's 160 KiB) however far the pool has grown.
 __global__ __launch_bounds__(1024) void k_mapgrid_build(MapArgs a) {
   const int b = blockIdx.x, cls = blockIdx.y, tid = threadIdx.x;
   const MapSeq& ms = a.seq[b];
-  const int n = ms.from_total[cls], nv = ms.n_valid, H = a.grid_H[cls];
+  const int n = ms.from_total[cls], nv = ms.n_valid, H = a.grid_H;
   const int* tab = a.tab + (long long)b * kTabInts;
   extern __shared__ __attribute__((aligned(16))) int mg_lds[];
   int* cnt = mg_lds;                       // [H]
@@ -1066,33 +997,9 @@ __device__ __forceinline__ float dist_to_map(const float4& p, mfloat2 sxy, float
   return (qxy.x + qxy.y) + ddz * ddz;                                         // FLANN L2_Simple, f32: (dx^2 + dy^2) + dz^2
 }
 
-struct Top5 {
-  float d[5]; int id[5]; float x[5], y[5], z[5];
-  __device__ __forceinline__ void init() {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) { d[k] = 3.0e38f; id[k] = 0x7fffffff; x[k] = y[k] = z[k] = 0.f; }
-  }
-  __device__ __forceinline__ void insert(float dd, int ii, float xx, float yy, float zz) {
-    if (!(dd < d[4] || (dd == d[4] && ii < id[4]))) return;
-    d[4] = dd; id[4] = ii; x[4] = xx; y[4] = yy; z[4] = zz;
-#pragma unroll
-    for (int s = 4; s >= 1; --s) {
-      const bool sw = d[s] < d[s - 1] || (d[s] == d[s - 1] && id[s] < id[s - 1]);
-      if (sw) {
-        float tf; int ti;
-        tf = d[s]; d[s] = d[s - 1]; d[s - 1] = tf;
-        ti = id[s]; id[s] = id[s - 1]; id[s - 1] = ti;
-        tf = x[s]; x[s] = x[s - 1]; x[s - 1] = tf;
-        tf = y[s]; y[s] = y[s - 1]; y[s - 1] = tf;
-        tf = z[s]; z[s] = z[s - 1]; z[s - 1] = tf;
-      }
-    }
-  }
-};
-
-// The same five as packed keys (f32 distance bits << 32 | submap index: one 64-bit compare orders by (distance, index), the order
-// Top5 keeps) + the position of the entry in the bucketed copy; coordinates are fetched through the position at the end: 15 registers
-// instead of 25, which is what takes k_map_search from 72 - 74 to <= 64 registers (eight waves per SIMD).
+// The five nearest as packed keys (f32 distance bits << 32 | submap index: one 64-bit compare orders by (distance, index)) + the position
+// of the entry in the bucketed copy; coordinates are fetched through the position at the end: 15 registers instead of the 25 five
+// neighbours with coordinates need, which is what takes k_map_search from 72 - 74 to 63 / 65 registers.
 struct Top5P {
   unsigned long long k[5]; int pos[5];
   __device__ __forceinline__ void init() {
@@ -1229,55 +1136,21 @@ __device__ __forceinline__ void lstsq_5x3(double a[5][3], double b[5], double x[
 
 }  // namespace
 
-#ifndef ALOAM_MAP_SEARCH_COOP
-#define ALOAM_MAP_SEARCH_COOP 0   // A/B builds: 1 = G lanes per query with LDS lists (round 5: measured slower, 5.72 against 4.65 ms)
-#endif
-#ifndef ALOAM_MAP_COOP_G0
-#define ALOAM_MAP_COOP_G0 8       // lanes per corner query
-#endif
-#ifndef ALOAM_MAP_COOP_G1
-#define ALOAM_MAP_COOP_G1 4       // lanes per surf query
-#endif
-#ifndef ALOAM_MAP_SEARCH_THREADS
-#define ALOAM_MAP_SEARCH_THREADS 256
-#endif
-constexpr int kMapSearchThreads = ALOAM_MAP_SEARCH_THREADS;
-#ifndef ALOAM_MAP_SEARCH_U
-#define ALOAM_MAP_SEARCH_U 4      // A/B builds: loads in flight per lane (measured, map_associate per step: 2: 7.76 ms, 4: 6.91, 6: 7.09, 8: 7.01)
-#endif
-#ifndef ALOAM_MAP_TOP5_PACKED
-#define ALOAM_MAP_TOP5_PACKED 1    // A/B builds: 0 = the five neighbours with their coordinates in registers (rounds 2 - 4)
-#endif
-#ifndef ALOAM_MAP_SEARCH_TAIL_AT
-#define ALOAM_MAP_SEARCH_TAIL_AT k   // what a lane past the end of its bucket loads in a group of U: its own entry k (A/B builds: 0 = entry 0, one line for all such lanes)
-#endif
-#ifndef ALOAM_MAP_SEARCH_TAILS
-#define ALOAM_MAP_SEARCH_TAILS 0   // A/B builds: 1 = full groups of U, then the rest under exec masks (round 5: 84 - 92 registers instead of 72 - 74, 5.00 against 4.70 ms)
-#endif
-#ifndef ALOAM_MAP_SEARCH_NBLK0
-#define ALOAM_MAP_SEARCH_NBLK0 16  // workgroups per sequence, corner / surf class (A/B builds)
-#endif
-#ifndef ALOAM_MAP_SEARCH_NBLK1
-#define ALOAM_MAP_SEARCH_NBLK1 48
-#endif
-#ifndef ALOAM_MAP_SEARCH_XCD
-#define ALOAM_MAP_SEARCH_XCD 1    // A/B builds: 0 = plain (block, sequence) grid
-#endif
+constexpr int kMapSearchThreads = 256;
+constexpr int kMapSearchU = 4;          // loads in flight per lane (measured, map_associate per step: 2: 7.76 ms, 4: 6.91, 6: 7.09, 8: 7.01)
+constexpr int kMapSearchBlocks[2] = {16, 48};   // workgroups per sequence, corner / surf class
 // Search half: lane per query, few registers, so that many waves hide the latency of the bucket walks.  Writes the five
 // neighbours (x, y, z each; ascending (distance, index)) or a "not found" mark to a.knn[query].
-#if !ALOAM_MAP_SEARCH_COOP
+// Rejected forms (measured slower in round 5, HISTORY.md): G lanes per query with LDS candidate lists ranked by counting, exact bucket
+// tails under exec masks, the five neighbours with their coordinates in registers, a plain (block, sequence) grid.
 template <int CLS>
 __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int nblk) {
   // XCD-aware work mapping (as in k_associate): workgroups are dealt round-robin over the 8 XCDs by linear id, and every XCD has its
-  // own L2.  The bucketed submap of a sequence (~0.7 MB) is read by all of that sequence's workgroups, so the 1-D grid is decoded
+  // own L2.  The bucketed submap of a sequence is read by all of that sequence's workgroups, so the 1-D grid is decoded
   // such that XCD x works through sequences x, x + 8, ...: one L2 fetches a sequence's submap instead of eight.
-#if ALOAM_MAP_SEARCH_XCD
   const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
   const int b = (slot / nblk) * 8 + xcd, blk = slot % nblk;
   if (b >= a.B) return;
-#else
-  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
-#endif
   const MapSeq& ms = a.seq[b];
   const int n = ms.n_stack[CLS];
   const long long sb = (long long)b * (CLS == 0 ? a.R * 120 : a.cap);
@@ -1285,7 +1158,7 @@ __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int
   double par[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
-  const int H = a.grid_H[CLS];
+  const int H = a.grid_H;
   const int* __restrict__ start = a.grid_start[CLS] + (long long)b * (H + 1);
   const float4* __restrict__ sorted = a.grid_sorted[CLS] + (long long)b * a.pool_cap;
   for (int i = blk * 256 + threadIdx.x; i < n; i += nblk * 256) {          // grid-stride over the stack
@@ -1293,11 +1166,7 @@ __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int
     const float gx = sel.x * kMapCellInv, gy = sel.y * kMapCellInv, gz = sel.z * kMapCellInv;
     const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
     const int nx = gx - (float)cx >= 0.5f ? cx + 1 : cx - 1, ny = gy - (float)cy >= 0.5f ? cy + 1 : cy - 1, nz = gz - (float)cz >= 0.5f ? cz + 1 : cz - 1;
-#if ALOAM_MAP_TOP5_PACKED
     Top5P top;
-#else
-    Top5 top;
-#endif
     top.init();
     // the reference discards the 5-NN result unless the 5th neighbour is closer than 1 m (:582, :650): collecting every point
     // with d < 1 from the 2x2x2 block and keeping the five smallest (distance, index) is an exact stand-in
@@ -1313,49 +1182,21 @@ __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int
     auto visit = [&](const float4& p, int at) {
       const float ddx = p.x - sel.x, ddy = p.y - sel.y, ddz = p.z - sel.z;
       const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;                   // FLANN L2_Simple, f32
-#if ALOAM_MAP_TOP5_PACKED
-      (void)at;
       if (d < 1.0f) top.insert(d, __float_as_int(p.w), at);
-#else
-      if (d < 1.0f) top.insert(d, __float_as_int(p.w), p.x, p.y, p.z);
-#endif
     };
-    constexpr int U = ALOAM_MAP_SEARCH_U;                                    // independent loads in flight per lane
+    constexpr int U = kMapSearchU;                                           // independent loads in flight per lane
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-#if ALOAM_MAP_SEARCH_TAILS
-      // Full groups of U, then the rest under exec masks: a lane only loads what its bucket holds.  (The L1 looks one line up per
-      // lane and load whatever the lane does with it: re-reading entry k in the lanes past the end, as rounds 2 - 4 did, cost a
-      // third of the surf class's look-ups.)
-      int k = s0[c];
-      for (; k + U <= s1[c]; k += U) {
-        float4 p[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = sorted[k + u];
-#pragma unroll
-        for (int u = 0; u < U; ++u) visit(p[u], k + u);
-      }
-      {
-        const int m = s1[c] - k;                                               // 0 .. U - 1 left
-        float4 p[U - 1];
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u) if (u < m) p[u] = sorted[k + u];
-#pragma unroll
-        for (int u = 0; u < U - 1; ++u) if (u < m) visit(p[u], k + u);
-      }
-#else
       for (int k = s0[c]; k < s1[c]; k += U) {
         const int m = s1[c] - k;
         float4 p[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) p[u] = sorted[u < m ? k + u : ALOAM_MAP_SEARCH_TAIL_AT];
+        for (int u = 0; u < U; ++u) p[u] = sorted[u < m ? k + u : k];        // a lane past the end of its bucket re-reads its own entry k
 #pragma unroll
         for (int u = 0; u < U; ++u) if (u < m) visit(p[u], k + u);
       }
-#endif
     }
     float4* out = a.knn + ((long long)b * a.cap + i) * 4;
-#if ALOAM_MAP_TOP5_PACKED
     if ((unsigned)(top.k[4] >> 32) < 0x3f800000u) {                          // pointSearchSqDis[4] < 1.0
       float4 q[5];
 #pragma unroll
@@ -1367,181 +1208,8 @@ __global__ __launch_bounds__(kMapSearchThreads) void k_map_search(MapArgs a, int
     } else {
       out[0] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-#else
-    const bool found = top.d[4] < 1.0f;                                      // pointSearchSqDis[4] < 1.0
-    out[0] = make_float4(top.x[0], top.y[0], top.z[0], found ? 1.f : 0.f);
-    out[1] = make_float4(top.x[1], top.y[1], top.z[1], top.x[2]);
-    out[2] = make_float4(top.y[2], top.z[2], top.x[3], top.y[3]);
-    out[3] = make_float4(top.z[3], top.x[4], top.y[4], top.z[4]);
-#endif
   }
 }
-#endif  // !ALOAM_MAP_SEARCH_COOP
-
-#if ALOAM_MAP_SEARCH_COOP
-// Round 5: G lanes per query (8 corner / 4 surf) instead of one.  The lane-per-query kernel of rounds 2 - 4 is bound by the L1's tag
-// look-ups: every lane walks ITS buckets 16 bytes at a time, so each wave-wide load touches ~50 different 128-byte lines and costs the
-// L1 ~48 cycles (measured: time = loads x 48 cycles per CU for both classes; without the sorted-five insertion only -12 %, with half
-// the candidates -35 %).  Here the G lanes of a group read G CONSECUTIVE entries of a bucket — one line per group and load, 8 - 16 lines
-// per wave-wide load instead of ~50 —, and what is kept per candidate is cheap: a candidate closer than 1 m is appended to the group's
-// list in LDS (key = distance bits << 32 | submap index, coordinates beside it; position from the group's bits of the wave ballot),
-// and when the eight buckets are through, every list entry gets its RANK among the keys of its list by counting (keys are distinct:
-// the index is in them) — rank r < 5 is the r-th neighbour in (distance, index) order, exactly the order the lane-per-query kernel's
-// sorted five had.  A list that is about to outgrow its K rows is cut down to its five smallest the same way and the walk goes on:
-// exact for any number of neighbours.  A wave serves 64 consecutive stack points: one lane per point for pointAssociateToMap (f64),
-// then G passes of 64 / G points.   reference: src/laserMapping.cpp:580-582,646-650 (nearestKSearch(pointSel, 5, ...), `< 1.0` gate).
-template <int CLS> struct MapCoop {
-  static constexpr int G = CLS == 0 ? ALOAM_MAP_COOP_G0 : ALOAM_MAP_COOP_G1;   // lanes per query
-  static constexpr int NQ = 64 / G;                                            // queries per pass
-  static constexpr int K = 4 * G;                                              // list rows per query: four own entries per lane in the ranking
-  static constexpr int OWN = K / G;
-  struct Lds {                                                                 // per wave
-    float4 sel[64];
-    unsigned long long key[NQ][K];
-    float xyz[NQ][K][3];
-    int2 hd[NQ][8];
-    float out[NQ][16];
-  };
-};
-template <int CLS>
-__global__ __launch_bounds__(256) void k_map_search(MapArgs a, int nblk) {
-  using C = MapCoop<CLS>;
-  constexpr int G = C::G, NQ = C::NQ, K = C::K, OWN = C::OWN;
-#if ALOAM_MAP_SEARCH_XCD
-  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
-  const int b = (slot / nblk) * 8 + xcd, blk = slot % nblk;
-  if (b >= a.B) return;
-#else
-  const int b = blockIdx.x / nblk, blk = blockIdx.x % nblk;
-#endif
-  const MapSeq& ms = a.seq[b];
-  const int n = ms.n_stack[CLS];
-  const long long sb = (long long)b * (CLS == 0 ? a.R * 120 : a.cap);
-  if (!ms.gate) return;
-  double par[7];
-#pragma unroll
-  for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
-  const int H = a.grid_H[CLS];
-  const char* __restrict__ start_b = reinterpret_cast<const char*>(a.grid_start[CLS] + (long long)b * (H + 1));
-  const char* __restrict__ sorted_b = reinterpret_cast<const char*>(a.grid_sorted[CLS] + (long long)b * a.pool_cap);
-  char* __restrict__ knn_b = reinterpret_cast<char*>(a.knn + (long long)b * a.cap * 4);
-  __shared__ typename C::Lds lds[4];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, grp = lane / G, l = lane % G;
-  typename C::Lds& W = lds[wave];
-  const unsigned below = (1u << l) - 1u;                                     // the lanes of my group in front of me
-  const int gshift = lane & ~(G - 1);
-
-  // rank of each of my OWN entries (e = l + G u < m) among the m keys of my group's list
-  auto ranks = [&](int m, unsigned long long* mine, int* rank) {
-#pragma unroll
-    for (int u = 0; u < OWN; ++u) { const int e = l + G * u; mine[u] = e < m ? W.key[grp][e] : ~0ull; rank[u] = 0; }
-    for (int j = 0; __any(j < m); ++j) {
-      const unsigned long long kj = j < m ? W.key[grp][j] : ~0ull;
-#pragma unroll
-      for (int u = 0; u < OWN; ++u) rank[u] += kj < mine[u] ? 1 : 0;
-    }
-  };
-
-  for (int base = (blk * 4 + wave) * 64; base < n; base += nblk * 256) {     // 64 consecutive stack points per wave and trip
-    const int i = base + lane;
-    {
-      float4 sel = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i < n) sel = associate_to_map(a.stack[CLS][sb + i], par);          // pointSel (:580, :646)
-      W.sel[lane] = make_float4(sel.x, sel.y, sel.z, i < n ? 1.f : 0.f);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-    for (int p = 0; p < G; ++p) {
-      const int q = p * NQ + grp;                                              // my group's query (of the wave's 64)
-      const float4 sel = W.sel[q];
-      const bool qlive = sel.w != 0.f;
-      const mfloat2 sxy = {sel.x, sel.y};
-      {
-        // heads of the eight buckets of the 2x2x2 block: lane l of the group fetches bucket l (and l + 4 when G = 4)
-        const float gx = sel.x * kMapCellInv, gy = sel.y * kMapCellInv, gz = sel.z * kMapCellInv;
-        const int cx = (int)floorf(gx), cy = (int)floorf(gy), cz = (int)floorf(gz);
-        const int nx = gx - (float)cx >= 0.5f ? cx + 1 : cx - 1, ny = gy - (float)cy >= 0.5f ? cy + 1 : cy - 1, nz = gz - (float)cz >= 0.5f ? cz + 1 : cz - 1;
-#pragma unroll
-        for (int c0 = 0; c0 < 8; c0 += G) {
-          const int c = c0 + l;
-          const unsigned h = map_bucket((c & 1) ? nx : cx, (c & 2) ? ny : cy, (c & 4) ? nz : cz, H);
-          int2 v = make_int2(0, 0);
-          if (qlive) { const MapIntPair t = *reinterpret_cast<const MapIntPair*>(start_b + (h << 2)); v = make_int2(t.a, t.b); }
-          W.hd[grp][c] = v;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      int kc[8], ke[8];                                                        // my next entry and the end of every bucket
-#pragma unroll
-      for (int c = 0; c < 8; ++c) { const int2 v = W.hd[grp][c]; kc[c] = v.x + l; ke[c] = v.y; }
-      int cnt = 0;
-      // Every point closer than 1 m lies in one of the eight cells, the eight cells sit in eight different buckets (map_bucket), and a
-      // point of another cell hashed into one of them fails d < 1: the lists hold exactly the neighbours within 1 m, each once.
-      for (;;) {
-        bool more = false;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) more = more || kc[c] < ke[c];
-        if (!__any(more)) break;
-        float4 pt[8];                                                          // all eight loads in flight, unconditionally (a lane beyond its
-#pragma unroll                                                                 // bucket reads entry 0: one line for all of them)
-        for (int c = 0; c < 8; ++c) pt[c] = *reinterpret_cast<const float4*>(sorted_b + ((unsigned)(kc[c] < ke[c] ? kc[c] : 0) << 4));
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          if (!__any(kc[c] < ke[c])) continue;
-          if (__any(cnt > K - G)) {                                            // a list could overflow in this step: cut it down to its five smallest
-            __builtin_amdgcn_wave_barrier();
-            unsigned long long mine[OWN]; int rank[OWN]; float mx[OWN], my[OWN], mz[OWN];
-            ranks(cnt, mine, rank);
-#pragma unroll
-            for (int u = 0; u < OWN; ++u) { const int e = l + G * u < cnt ? l + G * u : 0; mx[u] = W.xyz[grp][e][0]; my[u] = W.xyz[grp][e][1]; mz[u] = W.xyz[grp][e][2]; }
-            __builtin_amdgcn_wave_barrier();
-            if (cnt > K - G) {
-#pragma unroll
-              for (int u = 0; u < OWN; ++u)
-                if (l + G * u < cnt && rank[u] < 5) { W.key[grp][rank[u]] = mine[u]; W.xyz[grp][rank[u]][0] = mx[u]; W.xyz[grp][rank[u]][1] = my[u]; W.xyz[grp][rank[u]][2] = mz[u]; }
-              cnt = 5;
-            }
-            __builtin_amdgcn_wave_barrier();
-          }
-          const float d = dist_to_map(pt[c], sxy, sel.z);                      // FLANN L2_Simple, f32
-          const bool acc = kc[c] < ke[c] && d < 1.0f;
-          const unsigned bits = (unsigned)(__ballot(acc) >> gshift) & ((1u << G) - 1u);
-          if (acc) {
-            const int pos = cnt + __builtin_popcount(bits & below);
-            W.key[grp][pos] = (unsigned long long)__float_as_uint(d) << 32 | (unsigned)__float_as_int(pt[c].w);
-            W.xyz[grp][pos][0] = pt[c].x; W.xyz[grp][pos][1] = pt[c].y; W.xyz[grp][pos][2] = pt[c].z;
-          }
-          cnt += __builtin_popcount(bits);
-          kc[c] += G;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      // the five smallest keys in order -> the query's 64-byte record {x0 y0 z0 found | x1 y1 z1 x2 | y2 z2 x3 y3 | z3 x4 y4 z4}
-      {
-        unsigned long long mine[OWN]; int rank[OWN];
-        ranks(cnt, mine, rank);
-#pragma unroll
-        for (int u = 0; u < OWN; ++u) {
-          const int e = l + G * u;
-          if (e < cnt && rank[u] < 5) {
-            const int o = rank[u] == 0 ? 0 : 3 * rank[u] + 1;
-            W.out[grp][o] = W.xyz[grp][e][0]; W.out[grp][o + 1] = W.xyz[grp][e][1]; W.out[grp][o + 2] = W.xyz[grp][e][2];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (l == 0) W.out[grp][3] = cnt >= 5 ? 1.f : 0.f;                      // pointSearchSqDis[4] < 1.0  <=>  five points within 1 m
-        __builtin_amdgcn_wave_barrier();
-        if (qlive) {
-          char* rec = knn_b + ((unsigned)(base + q) << 6);
-          if (G == 8) *reinterpret_cast<float2*>(rec + l * 8) = *reinterpret_cast<const float2*>(&W.out[grp][2 * l]);
-          else *reinterpret_cast<float4*>(rec + l * 16) = *reinterpret_cast<const float4*>(&W.out[grp][4 * l]);
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-  }
-}
-#endif  // ALOAM_MAP_SEARCH_COOP
 
 // Fit half: line fit (corner) / plane fit (surf) in f64 on the five neighbours, validity tests, factor record.
 template <int CLS>
@@ -1641,10 +1309,7 @@ __global__ __launch_bounds__(256) void k_map_fit(MapArgs a) {
 // =======================================================================================================
 // solve
 // =======================================================================================================
-#ifndef ALOAM_MAP_SOLVE_THREADS
-#define ALOAM_MAP_SOLVE_THREADS 256
-#endif
-constexpr int kMapSolveThreads = ALOAM_MAP_SOLVE_THREADS;    // more waves do not pay: the kernel needs 256 VGPRs per lane for the f64 sums
+constexpr int kMapSolveThreads = 256;    // more waves do not pay: the kernel needs 256 VGPRs per lane for the f64 sums
 template <bool WITH_JAC>
 __device__ void map_evaluate(const MapArgs& a, int b, const int* s_pref, const double q[4], const double t[3], double* acc, int* n_edge, int* n_norm) {
   const int tid = threadIdx.x;
@@ -1917,6 +1582,55 @@ __global__ __launch_bounds__(256) void k_map_register(MapArgs a) {
 }
 
 // =======================================================================================================
+// pool occupancy report (host-side pool growth, aloam_capi.hip map_ensure_capacity)
+// =======================================================================================================
+// After every step: live points per (sequence, class) = sum of the cube populations (what the pool must hold at least), the largest of
+// them over the batch and the largest incoming stack so far, written to pinned host memory with the step number LAST, so that the host
+// can size the pools for the steps it is about to queue without waiting for the device.
+__global__ __launch_bounds__(256) void k_map_report(MapArgs a, int step) {
+  const int b = blockIdx.x, cls = blockIdx.y, tid = threadIdx.x;
+  const CubeDesc* T = cube_table(a, b, cls);
+  __shared__ int s_red[4][4];
+  __shared__ int s_last;
+  int live = 0;
+  for (int c = tid; c < kMapCubes; c += 256) live += T[c].cnt;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) live += __shfl_xor(live, d, 64);
+  if ((tid & 63) == 0) s_red[0][tid >> 6] = live;
+  __syncthreads();
+  if (tid == 0) {
+    live = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+    atomicExch(&a.live[b * 2 + cls], live);
+    __threadfence();
+    s_last = atomicAdd(&a.report_dev[0], 1) == (int)(gridDim.x * gridDim.y) - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;                                                       // the last workgroup to finish folds the batch
+  int m[4] = {0, 0, 0, 0};                                                   // live corner / surf, stack corner / surf
+  for (int i = tid; i < a.B; i += 256) {
+    m[0] = max(m[0], atomicAdd(&a.live[i * 2], 0)); m[1] = max(m[1], atomicAdd(&a.live[i * 2 + 1], 0));
+    m[2] = max(m[2], a.seq[i].n_stack[0]); m[3] = max(m[3], a.seq[i].n_stack[1]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m[k] = max(m[k], __shfl_xor(m[k], d, 64));
+    if ((tid & 63) == 0) s_red[k][tid >> 6] = m[k];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 0; k < 4; ++k) m[k] = max(max(s_red[k][0], s_red[k][1]), max(s_red[k][2], s_red[k][3]));
+    a.report_dev[0] = 0;
+    a.report_dev[1] = max(a.report_dev[1], m[2]);                            // largest stacks of any step so far
+    a.report_dev[2] = max(a.report_dev[2], m[3]);
+    volatile int* h = a.report_host;
+    h[1] = m[0]; h[2] = m[1]; h[3] = a.report_dev[1]; h[4] = a.report_dev[2];
+    __threadfence_system();
+    h[0] = step;
+  }
+}
+
+// =======================================================================================================
 // launchers
 // =======================================================================================================
 void launch_map_begin(const MapArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_map_begin, dim3(a.B), dim3(256), 0, s, a); }
@@ -1927,11 +1641,8 @@ void launch_map_cube_segments(const MapArgs& a, const VoxArgs& v, hipStream_t s)
   hipLaunchKernelGGL(k_map_cube_segments, dim3((a.B * 2 * kMapValidMax + 255) / 256), dim3(256), 0, s, a, v);
 }
 constexpr int kVoxSmallRuns = 8192, kVoxBigRuns = 24576;
-#ifndef ALOAM_VOX_BIG_THREADS
-#define ALOAM_VOX_BIG_THREADS 1024   // the 5 VGPRs this instance spills are values computed before the segment loop and reloaded once per segment (two scratch loads
-                                     // per 40 k-point segment); 768 threads (170 registers) and 512 threads (255) spill the same five: the allocator's choice, not the budget
-#endif
-constexpr int kVoxBigThreads = ALOAM_VOX_BIG_THREADS;
+constexpr int kVoxBigThreads = 1024;   // the 5 VGPRs this instance spills are values computed before the segment loop and reloaded once per segment (two scratch loads
+                                       // per 40 k-point segment); 768 threads (170 registers) and 512 threads (255) spill the same five: the allocator's choice, not the budget
 constexpr size_t vox_lds_bytes(int nt, int capr, int capn) { return (size_t)capr * 6 + (size_t)capn / 8 + 2 * 128 * (size_t)(nt / 64) + sizeof(int) * ((size_t)(capr / nt) * (nt / 64) + 1 + 48) + sizeof(float) * 6 * (nt / 64) + 64; }
 static_assert(vox_lds_bytes(kVoxBigThreads, kVoxBigRuns, kVoxBigN) <= 163840, "one workgroup may use the whole 160 KiB of a CU, not more");
 int prepare_voxel_filter() {     // the 1024-thread instance needs > 64 KiB of dynamic LDS (attribute of the function on the current device)
@@ -1956,30 +1667,20 @@ void launch_voxel_filter(const VoxArgs& v, int tile_bound, hipStream_t s) {
   hipLaunchKernelGGL(k_vox_copyback, dim3(tile_bound), dim3(256), 0, s, v);
 }
 static size_t mapgrid_lds_bytes(int H) { return sizeof(int) * ((size_t)H + 1024 + 160); }
+static_assert(sizeof(int) * ((size_t)kMapGridMaxH + 1024 + 160) <= 163840, "the bucket table of k_mapgrid_build must fit one CU's LDS");
 int prepare_map_grid(int H) {
-  if (H > 16384) return 0;                 // larger tables use the global counting sort
+  if (H > kMapGridMaxH || H < 1024 || (H & (H - 1))) return -1;
   return hipFuncSetAttribute((const void*)k_mapgrid_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mapgrid_lds_bytes(H)) == hipSuccess ? 0 : -1;
 }
 void launch_map_grid(const MapArgs& a, hipStream_t s) {
-  if (a.grid_H[0] <= 16384 && a.grid_H[1] <= 16384 && a.grid_H[0] == a.grid_H[1]) {
-    hipLaunchKernelGGL(k_mapgrid_build, dim3(a.B, 2), dim3(1024), mapgrid_lds_bytes(a.grid_H[0]), s, a);
-    return;
-  }
-  for (int cls = 0; cls < 2; ++cls) (void)hipMemsetAsync(a.grid_cnt[cls], 0, sizeof(int) * (size_t)a.B * a.grid_H[cls], s);
-  const dim3 g(32, a.B, 2);                              // grid-stride over the submap of each (sequence, class)
-  hipLaunchKernelGGL(k_mapgrid_count, g, dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_mapgrid_scan, dim3(a.B, 2), dim3(1024), 0, s, a);
-  hipLaunchKernelGGL(k_mapgrid_fill, g, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_mapgrid_build, dim3(a.B, 2), dim3(1024), mapgrid_lds_bytes(a.grid_H), s, a);
 }
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s) {
   const int by = (a.B + 7) / 8 * 8;                      // padded so that every (XCD, sequence slot) pair exists
   (void)iter;
-#ifndef ALOAM_MAP_DEBUG_LDS
-#define ALOAM_MAP_DEBUG_LDS 0      // occupancy experiments: dynamic LDS bytes per search workgroup (nothing uses them)
-#endif
-  hipLaunchKernelGGL(k_map_search<0>, dim3(ALOAM_MAP_SEARCH_NBLK0 * by), dim3(kMapSearchThreads), ALOAM_MAP_DEBUG_LDS, s, a, ALOAM_MAP_SEARCH_NBLK0);
+  hipLaunchKernelGGL(k_map_search<0>, dim3(kMapSearchBlocks[0] * by), dim3(kMapSearchThreads), 0, s, a, kMapSearchBlocks[0]);
   hipLaunchKernelGGL(k_map_fit<0>, dim3(16, a.B), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(k_map_search<1>, dim3(ALOAM_MAP_SEARCH_NBLK1 * by), dim3(kMapSearchThreads), ALOAM_MAP_DEBUG_LDS, s, a, ALOAM_MAP_SEARCH_NBLK1);
+  hipLaunchKernelGGL(k_map_search<1>, dim3(kMapSearchBlocks[1] * by), dim3(kMapSearchThreads), 0, s, a, kMapSearchBlocks[1]);
   hipLaunchKernelGGL(k_map_fit<1>, dim3(48, a.B), dim3(256), 0, s, a);
 }
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s) {
@@ -1994,5 +1695,6 @@ void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s) {
   hipLaunchKernelGGL(k_map_scatter, dim3(a.B, 2), dim3(64), 0, s, a);
 }
 void launch_map_register(const MapArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_map_register, dim3((a.cap + 255) / 256, a.B), dim3(256), 0, s, a); }
+void launch_map_report(const MapArgs& a, int step, hipStream_t s) { hipLaunchKernelGGL(k_map_report, dim3(a.B, 2), dim3(256), 0, s, a, step); }
 
 }  // namespace aloam

@@ -6,6 +6,7 @@ namespace aloam {
 
 constexpr int kMapW = 21, kMapH = 21, kMapD = 11, kMapCubes = kMapW * kMapH * kMapD;   // reference src/laserMapping.cpp:75-80
 constexpr int kMapValidMax = 75;                                                       // 5 x 5 x 3 window (:512-529)
+constexpr int kMapGridMaxH = 32768;                                                    // bucket table of k_mapgrid_build (LDS)
 constexpr int kVoxTile = 2048;                                                         // keys per sort tile (general path)
 constexpr int kVoxTinyN = 2048, kVoxSmallN = 8192, kVoxBigN = 65536;                                    // segment sizes the single-workgroup LDS filter takes (256 / 1024 threads)
 
@@ -36,17 +37,9 @@ struct alignas(16) MapSeq {                              // one per sequence
 // Factor records of the valid stack points (k_map_fit -> k_map_solve; every LM evaluation streams them again, and k_map_solve runs at HBM
 // speed: bytes are its time).  curr_point is a float point of the stack, so it is kept as three floats (the same doubles come back when it
 // is read): 64 / 48 bytes instead of 80 / 64.  pad: the stack index of the point.
-#ifndef ALOAM_MAP_REC_F32CP
-#define ALOAM_MAP_REC_F32CP 1      // A/B builds: 0 = curr_point as three doubles + a `valid` word (rounds 2 - 4)
-#endif
-#if ALOAM_MAP_REC_F32CP
 struct MapEdgeRec { double a[3], b[3]; float cp[3]; int pad; };         // LidarEdgeFactor(curr_point, point_a, point_b, 1.0)      (:618)
 struct MapNormRec { double n[3], d; float cp[3]; int pad; };            // LidarPlaneNormFactor(curr_point, norm, negative_OA_dot_norm) (:683)
 static_assert(sizeof(MapEdgeRec) == 64 && sizeof(MapNormRec) == 48, "record sizes");
-#else
-struct MapEdgeRec { double cp[3], a[3], b[3]; int valid, pad; };
-struct MapNormRec { double cp[3], n[3], d; int valid, pad; };
-#endif
 
 struct VoxSeg {                                          // one pcl::VoxelGrid::filter call
   const float4* in;
@@ -98,8 +91,10 @@ struct MapArgs {
   int* compact_flag;             // [B][2]
   float4* grid_sorted[2];        // [B][pool_cap]
   int* grid_start[2];            // [B][H + 1]
-  int* grid_cnt[2];              // [B][H]
-  int grid_H[2];
+  int grid_H;                    // buckets of the submap hash, the same for both classes
+  int* live;                     // [B][2] live points of every (sequence, class) after the step (k_map_report)
+  int* report_dev;               // [3] ticket of k_map_report, largest corner / surf stack so far
+  int* report_host;              // pinned host memory: step, largest live corner / surf, largest stack corner / surf
   float4* knn;                   // [B][cap][4]  the five neighbours of every stack point (search -> fit)
   MapEdgeRec* edges;             // [B][R*120]
   MapNormRec* norms;             // [B][cap]
@@ -121,5 +116,6 @@ void launch_map_associate(const MapArgs& a, int iter, hipStream_t s);
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s);
 void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s);   // staging: 2 pools per sequence
 void launch_map_register(const MapArgs& a, hipStream_t s);
+void launch_map_report(const MapArgs& a, int step, hipStream_t s);
 
 }  // namespace aloam

@@ -118,6 +118,82 @@ def make_world(seed: int, n_boxes: int = 40, n_poles: int = 30, half_extent: flo
     return World(half_extent, torch.cat([bxy, cz[:, None]], dim=1), half, torch.stack([torch.cos(yaw), torch.sin(yaw)], dim=1), pxy, pr, ptop)
 
 
+STREET_AMP, STREET_WAVELENGTH, STREET_MAX_RANGE = 25.0, 320.0, 120.0
+
+
+def _street_y(x):
+    return STREET_AMP * torch.sin(2.0 * math.pi * x / STREET_WAVELENGTH)
+
+
+def make_street_world(seed: int, length: float = 700.0) -> World:
+    """A world to TRAVEL through (non-returning trajectories, `trajectory_travel`): a gently winding street of `length` metres along x
+    (centre line y = 25 sin(2 pi x / 320)) with a yawed box every ~14 m on either side (9 - 22 m off the centre line) and a pole every
+    ~11 m (4.5 - 7 m off it), so that a sensor with a 120 m range always sees both feature classes.  The map window of the reference's
+    mapping node (21 x 21 x 11 cubes of 50 m around the FIRST pose, src/laserMapping.cpp:72-80) only shifts once the sensor is more
+    than 375 m from where it started (:323-507): that is what the length is for."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    dt = torch.float64
+    xs_b, xs_p = [], []
+    for side in (-1.0, 1.0):
+        x = -length / 2 + 5.0 + 7.0 * float(torch.rand(1, generator=g, dtype=dt))
+        while x < length / 2 - 5.0:
+            xs_b.append((x, side))
+            x += 11.0 + 6.0 * float(torch.rand(1, generator=g, dtype=dt))
+    x = -length / 2 + 3.0
+    k = 0
+    while x < length / 2 - 3.0:
+        xs_p.append((x, -1.0 if k % 2 else 1.0))
+        x += 8.0 + 6.0 * float(torch.rand(1, generator=g, dtype=dt))
+        k += 1
+    nb, npole = len(xs_b), len(xs_p)
+    bx = torch.tensor([v[0] for v in xs_b], dtype=dt)
+    bs = torch.tensor([v[1] for v in xs_b], dtype=dt)
+    size = torch.rand(nb, 3, generator=g, dtype=dt)
+    half = torch.stack([1.5 + 4.0 * size[:, 0], 1.5 + 4.0 * size[:, 1], 1.5 + 5.0 * size[:, 2]], dim=1)
+    off = 9.0 + torch.linalg.norm(half[:, :2], dim=1) + 8.0 * torch.rand(nb, generator=g, dtype=dt)      # clear of the centre line whatever the yaw
+    by = _street_y(bx) + bs * off
+    cz = -SENSOR_HEIGHT + half[:, 2]
+    yaw = torch.rand(nb, generator=g, dtype=dt) * math.pi
+    px = torch.tensor([v[0] for v in xs_p], dtype=dt)
+    ps = torch.tensor([v[1] for v in xs_p], dtype=dt)
+    py = _street_y(px) + ps * (4.5 + 2.5 * torch.rand(npole, generator=g, dtype=dt))
+    pr = 0.12 + 0.25 * torch.rand(npole, generator=g, dtype=dt)
+    ptop = -SENSOR_HEIGHT + 3.0 + 6.0 * torch.rand(npole, generator=g, dtype=dt)
+    return World(length / 2 + 60.0, torch.stack([bx, by, cz], dim=1), half, torch.stack([torch.cos(yaw), torch.sin(yaw)], dim=1),
+                 torch.stack([px, py], dim=1), pr, ptop)
+
+
+def trajectory_travel(n_frames: int, step: float = 1.6, seed: int = 0, length: float = 700.0, ramp: int = 10):
+    """Poses along the street of `make_street_world`, never returning: starts at x = -3/4 wavelength (where the street runs parallel to x, so the
+    map frame of the reference - the first pose - is the world's up to the small roll / pitch) and advances `step` metres of arc
+    per sweep (ramping up over the first `ramp` sweeps: the odometry's first solve starts from the identity, reference
+    src/laserOdometry.cpp:97-98), heading along the tangent, with the small roll / pitch / height oscillations of `trajectory`."""
+    g = torch.Generator().manual_seed(2000 + seed)
+    ph = torch.rand(3, generator=g, dtype=torch.float64) * 2 * math.pi
+    k = torch.arange(n_frames, dtype=torch.float64)
+    ds = step * torch.clamp((k + 1.0) / float(ramp + 1), max=1.0)
+    xs = [-0.75 * STREET_WAVELENGTH]
+    assert xs[0] > -length / 2 + 60.0
+    for i in range(1, n_frames):
+        x = xs[-1]
+        slope = STREET_AMP * 2.0 * math.pi / STREET_WAVELENGTH * math.cos(2.0 * math.pi * x / STREET_WAVELENGTH)
+        xs.append(x + float(ds[i]) / math.sqrt(1.0 + slope * slope))
+    x = torch.tensor(xs, dtype=torch.float64)
+    assert float(x[-1]) < length / 2 - 20.0, "trajectory leaves the street: raise `length`"
+    slope = STREET_AMP * 2.0 * math.pi / STREET_WAVELENGTH * torch.cos(2.0 * math.pi * x / STREET_WAVELENGTH)
+    t = torch.stack([x, _street_y(x), 0.05 * torch.sin(0.31 * k + ph[0])], dim=1)
+    return _rpy_matrices(torch.atan(slope), torch.deg2rad(torch.tensor(0.4, dtype=torch.float64)) * torch.sin(0.23 * k + ph[1]),
+                         torch.deg2rad(torch.tensor(0.3, dtype=torch.float64)) * torch.sin(0.17 * k + ph[2])), t
+
+
+def _rpy_matrices(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = torch.cos(yaw), torch.sin(yaw), torch.cos(pitch), torch.sin(pitch), torch.cos(roll), torch.sin(roll)
+    return torch.stack([
+        torch.stack([cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr], dim=1),
+        torch.stack([sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr], dim=1),
+        torch.stack([-sp, cp * sr, cp * cr], dim=1)], dim=1)
+
+
 def trajectory(n_frames: int, step: float = 1.0, radius: float = 30.0, seed: int = 0, start_angle: float = 0.0):
     """Poses (R [n,3,3], t [n,3], float64) of the sensor in the world: a circle of `radius` driven `step`
     metres per sweep with small roll / pitch / height oscillations (6-DoF motion)."""
@@ -138,7 +214,8 @@ def trajectory(n_frames: int, step: float = 1.0, radius: float = 30.0, seed: int
 
 
 def render_scan(world: World, model: SensorModel, R: torch.Tensor, t: torch.Tensor, noise_sigma: float,
-                generator: torch.Generator | None = None, nan_fraction: float = 0.0, rough: bool = False) -> torch.Tensor:
+                generator: torch.Generator | None = None, nan_fraction: float = 0.0, rough: bool = False, max_range: float = 200.0,
+                cull: bool = False) -> torch.Tensor:
     """Ray-cast one sweep.  Returns float32 [N, 4] (x, y, z, field) in the SENSOR frame and scan order; the 4th
     float is the ring index for ROWS128 and 0 otherwise.  Rays without a return are dropped (as a real
     driver does); `nan_fraction` replaces that share of the returns by NaN to exercise the NaN filter.
@@ -151,6 +228,10 @@ def render_scan(world: World, model: SensorModel, R: torch.Tensor, t: torch.Tens
     dt = torch.float64
     R = R.to(dev, dt)
     o = t.to(dev, dt)
+    if cull:       # only the obstacles that can lie within `max_range` (big worlds); leaves every return unchanged
+        kb = torch.linalg.norm(world.box_c[:, :2] - o[None, :2], dim=1) < max_range + 12.0
+        kp = torch.linalg.norm(world.pole_c - o[None, :2], dim=1) < max_range + 1.0
+        world = World(world.half_extent, world.box_c[kb], world.box_h[kb], world.box_cs[kb], world.pole_c[kp], world.pole_r[kp], world.pole_top[kp])
     d = model.dirs @ R.T                                    # world-frame directions [N,3]
     inf = torch.full((d.shape[0],), float("inf"), dtype=dt, device=dev)
     best = inf.clone()
@@ -197,7 +278,7 @@ def render_scan(world: World, model: SensorModel, R: torch.Tensor, t: torch.Tens
     okc = (disc > 0) & (tc > 0) & (zc <= world.pole_top[None]) & (zc >= -SENSOR_HEIGHT)
     best = torch.minimum(best, torch.where(okc, tc, torch.full_like(tc, float("inf"))).amin(dim=1))
 
-    valid = torch.isfinite(best) & (best < 200.0)
+    valid = torch.isfinite(best) & (best < max_range)
     if generator is not None:
         noise = torch.randn(best.shape, generator=generator, dtype=dt, device=generator.device).to(dev)
     else:
@@ -241,14 +322,20 @@ def render_scan(world: World, model: SensorModel, R: torch.Tensor, t: torch.Tens
 
 def make_sequence(model_name: str, n_frames: int, seed: int, noise_sigma: float | None = None, device="cpu",
                   world_seed: int | None = None, step: float = 1.0, nan_fraction: float = 0.0, columns: int | None = None, rough: bool = False,
-                  az_offset: float = 0.0):
-    """Returns (scans: list of float32 [N_i,4] tensors, R [n,3,3], t [n,3], model)."""
+                  az_offset: float = 0.0, travel: bool = False, street_length: float = 700.0):
+    """Returns (scans: list of float32 [N_i,4] tensors, R [n,3,3], t [n,3], model).  `travel`: a non-returning drive down the street of
+    `make_street_world` (`step` metres per sweep, 120 m sensor range) instead of laps of the 30 m circle."""
     model = sensor_model(model_name, columns=columns, device=device, az_offset=az_offset)
-    world = make_world(seed if world_seed is None else world_seed).to(device)
     if noise_sigma is None:
         noise_sigma = 0.01 if model_name == "VLP-16" else 0.02
-    R, t = trajectory(n_frames, step=step, seed=seed, start_angle=0.37 * seed)
     gen = torch.Generator(device=device).manual_seed(77 + seed)
+    if travel:
+        world = make_street_world(seed if world_seed is None else world_seed, street_length).to(device)
+        R, t = trajectory_travel(n_frames, step=step, seed=seed, length=street_length)
+        scans = [render_scan(world, model, R[k], t[k], noise_sigma, gen, nan_fraction, rough, max_range=STREET_MAX_RANGE, cull=True) for k in range(n_frames)]
+        return scans, R, t, model
+    world = make_world(seed if world_seed is None else world_seed).to(device)
+    R, t = trajectory(n_frames, step=step, seed=seed, start_angle=0.37 * seed)
     scans = [render_scan(world, model, R[k], t[k], noise_sigma, gen, nan_fraction, rough) for k in range(n_frames)]
     return scans, R, t, model
 

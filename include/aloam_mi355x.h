@@ -120,16 +120,27 @@ int aloam_process_host(aloam_ctx* ctx, const void* h_scans, long long seq_stride
 /* Replaces the node's globals (cube arrays laserCloudCornerArray / SurfArray[4851], q_wmap_wodom, t_wmap_wodom, `parameters`,
  * laserCloudCen*; src/laserMapping.cpp:72-116) and reads the launch parameters mapping_line_resolution / mapping_plane_resolution
  * (:898-905).  pool_points = capacity of the device-resident map per sequence and feature class.  Call once, before the first step. */
-/* Limits: the map of one sequence and class lives in pool_points points (cubes grow by doubling, the pool is compacted when
- * fragmented); one cube may hold up to the whole pool.  Frames whose points do not fit are counted on the device; the first
- * aloam_synchronize after such a step returns ALOAM_E_CAPACITY once (however many asynchronous steps were queued in between), then
- * ALOAM_OK again until it happens anew. */
+/* pool_points is where the map STARTS: the reference's cubes are std::vectors that grow as long as the sensor travels
+ * (src/laserMapping.cpp:737-783), so the pools (one per sequence and class; cubes grow by doubling inside it, the pool is compacted when
+ * fragmented; one cube may hold up to the whole pool) are doubled - between steps, contents moved, at aloam_mapping_step - whenever the
+ * live points plus what the queued steps can add would no longer fit, up to aloam_mapping_set_pool_limit (default 2^26 points, or
+ * whatever the device memory holds).  Only at that ceiling do points get dropped: such frames are counted on the device and the first
+ * aloam_synchronize after one returns ALOAM_E_CAPACITY once (however many asynchronous steps were queued in between), then ALOAM_OK
+ * again until it happens anew. */
 int aloam_mapping_enable(aloam_ctx* ctx, float mapping_line_resolution, float mapping_plane_resolution, int pool_points);
+int aloam_mapping_set_pool_limit(aloam_ctx* ctx, int max_pool_points);   /* ceiling of the pool growth, per sequence and class; before or after enable */
+/* out: current pool_points, growths so far, the limit, live points of the fullest (sequence, class) pool after the last finished step */
+int aloam_get_map_pool_info(aloam_ctx* ctx, int out[4]);
 /* One frame for every sequence, asynchronous.  Consumes what the odometry node publishes for the frame — /laser_cloud_corner_last,
  * /laser_cloud_surf_last, /velodyne_cloud_3, /laser_odom_to_init (src/laserOdometry.cpp:508-591) — straight from the context
  * (call after aloam_odometry_step / aloam_process_device), or as injected through aloam_set_last / aloam_set_full_cloud / aloam_set_state. */
 int aloam_mapping_step(aloam_ctx* ctx);
 int aloam_set_full_cloud(aloam_ctx* ctx, int seq, const float* cloud_xyzw, int n);          /* /velodyne_cloud_3 (src/laserMapping.cpp:189-194) */
+/* State injection, mapping node: laserCloudCornerArray / SurfArray (feature_class 0 / 1) of one sequence replaced by n_cubes cubes
+ * (window indices i + 21 j + 441 k as src/laserMapping.cpp:527, their populations, their points back to back), and
+ * laserCloudCenWidth / Height / Depth, q_wmap_wodom, t_wmap_wodom, frameCount (src/laserMapping.cpp:72-74,84-91,115-116). */
+int aloam_set_map(aloam_ctx* ctx, int seq, int feature_class, const int* cube_ids, const int* counts, int n_cubes, const float* points_xyzw);
+int aloam_set_map_frame(aloam_ctx* ctx, int seq, const int cen[3], const double q_wmap_wodom[4], const double t_wmap_wodom[3], int frame_count);
 /* /aft_mapped_to_init pose = q_w_curr, t_w_curr (src/laserMapping.cpp:851-863) and the map<-odom correction (:148-152) */
 int aloam_get_map_pose(aloam_ctx* ctx, int seq, double q_w_curr[4], double t_w_curr[3], double q_wmap_wodom[4], double t_wmap_wodom[3]);
 /* laserCloudCenWidth/Height/Depth, frameCount, submap sizes (corner, surf), stack sizes (corner, surf), factors per iteration

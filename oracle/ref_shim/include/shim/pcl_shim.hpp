@@ -6,7 +6,8 @@
 //   VoxelGrid<PointT>::applyFilter   pcl/filters/impl/voxel_grid.hpp (min/max -> integer cell index -> std::sort by cell
 //                                    -> per-cell centroid of ALL fields, downsample_all_data = true, min_points 0)
 //   KdTreeFLANN<PointT>              exact (eps = 0) k-NN over x,y,z with FLANN's L2_Simple f32 accumulation; written
-//                                    here as a brute-force scan, which is result-equivalent except on exact ties
+//                                    here as a median-split tree that returns what a brute-force scan ordered by
+//                                    (distance, index) returns - result-equivalent to FLANN except on exact ties
 //   fromROSMsg / toROSMsg            field lookup by name / the PointXYZI wire layout (x@0 y@4 z@8 intensity@16, step 32)
 //   removeNaNFromPointCloud          pcl/filters/impl/filter.hpp
 #pragma once
@@ -178,39 +179,79 @@ class VoxelGrid {
 };
 
 // ---- KdTreeFLANN ----------------------------------------------------------------------------------------------
+// Exact k-NN with FLANN's L2_Simple arithmetic (f32, the three squared differences added x -> y -> z) and results in ascending
+// (distance, index) order - the order a brute-force scan with that key produces; a median-split tree over the finite points only prunes
+// sub-trees that cannot hold a smaller key.  The pruning bound is the squared f32 distance to the splitting plane: rounding is monotone,
+// so every point beyond the plane has a distance that is no smaller, and `<=` keeps equal distances with a lower index reachable.
+// (The true FLANN breaks exact ties in traversal order, which is not restated here; SURVEY.md Appendix C.)
 template <class PointT>
 class KdTreeFLANN {
  public:
   typedef std::shared_ptr<KdTreeFLANN<PointT>> Ptr;
   void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) {
-    cloud_ = c; idx_.clear();
+    cloud_ = c; idx_.clear(); nodes_.clear();
     for (size_t i = 0; i < c->points.size(); ++i) {
       const PointT& p = c->points[i];
       if (std::isfinite(p.x) && std::isfinite(p.y) && std::isfinite(p.z)) idx_.push_back(static_cast<int>(i));
     }
+    if (!idx_.empty()) { nodes_.reserve(idx_.size() / 4 + 8); build(0, static_cast<int>(idx_.size())); }
   }
   int nearestKSearch(const PointT& q, int k, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances) const {
     if (k > static_cast<int>(idx_.size())) k = static_cast<int>(idx_.size());
     k_indices.resize(k); k_sqr_distances.resize(k);
     if (k == 0) return 0;
     std::vector<std::pair<float, int>> best;    // ascending (distance, index), at most k entries
-    for (int i : idx_) {
-      const PointT& p = cloud_->points[i];
-      float d = 0.f;
-      float diff = p.x - q.x; d += diff * diff;
-      diff = p.y - q.y; d += diff * diff;
-      diff = p.z - q.z; d += diff * diff;
-      if (static_cast<int>(best.size()) == k && !(d < best.back().first)) continue;
-      auto it = std::upper_bound(best.begin(), best.end(), std::make_pair(d, i));
-      best.insert(it, std::make_pair(d, i));
-      if (static_cast<int>(best.size()) > k) best.pop_back();
-    }
+    best.reserve(k + 1);
+    const float qv[3] = {q.x, q.y, q.z};
+    search(0, qv, k, best);
     for (int j = 0; j < k; ++j) { k_indices[j] = best[j].second; k_sqr_distances[j] = best[j].first; }
     return k;
   }
  private:
+  struct Node { int lo, hi, left, right, axis; float split; };   // leaf: left < 0, points idx_[lo, hi)
+  static float coord(const PointT& p, int a) { return a == 0 ? p.x : (a == 1 ? p.y : p.z); }
+  int build(int lo, int hi) {
+    const int id = static_cast<int>(nodes_.size());
+    nodes_.push_back(Node{lo, hi, -1, -1, 0, 0.f});
+    if (hi - lo <= 12) return id;
+    float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()}, mx[3] = {-mn[0], -mn[0], -mn[0]};
+    for (int i = lo; i < hi; ++i) for (int a = 0; a < 3; ++a) { const float v = coord(cloud_->points[idx_[i]], a); mn[a] = std::min(mn[a], v); mx[a] = std::max(mx[a], v); }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a) if (mx[a] - mn[a] > mx[axis] - mn[axis]) axis = a;
+    if (!(mx[axis] > mn[axis])) return id;                        // all points coincide: one leaf
+    const int mid = lo + (hi - lo) / 2;
+    std::nth_element(idx_.begin() + lo, idx_.begin() + mid, idx_.begin() + hi,
+                     [&](int x, int y) { return coord(cloud_->points[x], axis) < coord(cloud_->points[y], axis); });
+    const float split = coord(cloud_->points[idx_[mid]], axis);   // left: <= split, right: >= split
+    const int l = build(lo, mid), r = build(mid, hi);
+    nodes_[id].left = l; nodes_[id].right = r; nodes_[id].axis = axis; nodes_[id].split = split;
+    return id;
+  }
+  void search(int id, const float q[3], int k, std::vector<std::pair<float, int>>& best) const {
+    const Node& n = nodes_[id];
+    if (n.left < 0) {
+      for (int j = n.lo; j < n.hi; ++j) {
+        const int i = idx_[j];
+        const PointT& p = cloud_->points[i];
+        float d = 0.f;
+        float diff = p.x - q[0]; d += diff * diff;
+        diff = p.y - q[1]; d += diff * diff;
+        diff = p.z - q[2]; d += diff * diff;
+        const std::pair<float, int> key(d, i);
+        if (static_cast<int>(best.size()) == k && !(key < best.back())) continue;
+        best.insert(std::upper_bound(best.begin(), best.end(), key), key);
+        if (static_cast<int>(best.size()) > k) best.pop_back();
+      }
+      return;
+    }
+    const float diff = n.split - q[n.axis];
+    const int near = diff >= 0.f ? n.left : n.right, far = diff >= 0.f ? n.right : n.left;
+    search(near, q, k, best);
+    if (static_cast<int>(best.size()) < k || diff * diff <= best.back().first) search(far, q, k, best);
+  }
   typename PointCloud<PointT>::ConstPtr cloud_;
   std::vector<int> idx_;
+  std::vector<Node> nodes_;
 };
 
 }  // namespace pcl

@@ -203,7 +203,7 @@ def test_map_pool_compaction(O, binding):
     orc = O.Oracle(16, 0.3, lm_max_iterations=0)
     orc.map_config(0.4, 0.8)
     gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=1, max_points=8192, lm_max_iterations=0)
-    gpu.mapping_enable(0.4, 0.8, pool_points=40960)
+    gpu.mapping_enable(0.4, 0.8, pool_points=40960, pool_limit=40960)        # a pool that may not grow: compaction has to do it
     for k in range(18):
         corner = rng.uniform(-10, 10, (1500, 4)).astype(np.float32); corner[:, 3] = rng.integers(0, 16, 1500)
         surf = rng.uniform(-20, 20, (3000, 4)).astype(np.float32); surf[:, 2] *= 0.01; surf[:, 3] = rng.integers(0, 16, 3000)
@@ -220,13 +220,40 @@ def test_map_pool_compaction(O, binding):
     gpu.close()
 
 
+def test_map_pool_growth_keeps_the_map_bit_exact(O, binding):
+    """The reference's cubes are std::vectors (src/laserMapping.cpp:737-783): a map grows as long as points arrive.  A pool that starts at 8192
+    points per class must double again and again under the same load as above - no point dropped (aloam_synchronize would raise), the whole
+    map bit-exact against the oracle after every frame (solver off), the growths reported."""
+    rng = np.random.default_rng(12)
+    orc = O.Oracle(16, 0.3, lm_max_iterations=0)
+    orc.map_config(0.4, 0.8)
+    gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=1, max_points=8192, lm_max_iterations=0)
+    gpu.mapping_enable(0.4, 0.8, pool_points=8192)
+    pools = []
+    for k in range(14):
+        corner = rng.uniform(-10 - 2 * k, 10 + 2 * k, (1500, 4)).astype(np.float32); corner[:, 3] = rng.integers(0, 16, 1500)
+        surf = rng.uniform(-20 - 4 * k, 20 + 4 * k, (3000, 4)).astype(np.float32); surf[:, 2] *= 0.01; surf[:, 3] = rng.integers(0, 16, 3000)
+        q, t = np.array([0, 0, 0, 1.0]), np.array([0.01 * k, 0, 0])
+        orc.mapping_step(q, t, corner, surf, surf[:10])
+        gpu.set_last(corner, surf, 0); gpu.set_full_cloud(surf[:10], 0); gpu.set_state([0, 0, 0, 1], [0, 0, 0], q, t, 0)
+        gpu.mapping_step()
+        gpu.synchronize()
+        for cls in (0, 1):
+            _compare_maps(gpu.map_cubes(cls), orc.map_cubes(cls), (k, cls))
+        pools.append(gpu.map_pool_info())
+    live = max(sum(len(v) for v in gpu.map_cubes(cls).values()) for cls in (0, 1))
+    assert pools[-1]["growths"] >= 2 and pools[-1]["pool_points"] >= 32768 and pools[-1]["live_max"] == live, (pools[-1], live)
+    assert all(p["live_max"] <= p["pool_points"] for p in pools)
+    gpu.close()
+
+
 def test_capacity_errors_of_unsynchronised_steps_are_not_lost(binding):
     """Asynchronous use (bench.py queues many steps and synchronises once): a step that runs out of map pool is followed by steps
     that fit.  The per-step flag is cleared by the next step, but aloam_synchronize must still report ALOAM_E_CAPACITY — once —
     and the map must hold the points of the steps that did fit."""
     rng = np.random.default_rng(5)
     gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=2, max_points=16384, lm_max_iterations=0)
-    gpu.mapping_enable(0.4, 0.8, pool_points=4096)
+    gpu.mapping_enable(0.4, 0.8, pool_points=4096, pool_limit=4096)            # at its ceiling from the start
 
     def frame(n_surf, seq_with_points, half):
         for b in range(2):

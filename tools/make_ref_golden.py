@@ -215,8 +215,76 @@ def main_full_mapping():
         print(path, os.path.getsize(path) // 1024, "KiB", [int(out[f"corner_map_cnt{k}"].sum()) for k in range(frames)], [int(out[f"surf_map_cnt{k}"].sum()) for k in range(frames)])
 
 
+# Long horizon on a TRAVELLING sensor: the reference's three translation units end to end over hundreds of sweeps of a non-returning drive
+# (a-loam_amd/synthetic.py `travel`: ~445 m down a 700 m street), so that the pose chain integrates without renormalisation for 300 frames
+# (src/laserOdometry.cpp:504-505), the submap is gathered from changing cubes (src/laserMapping.cpp:509-539), the cubes grow and are re-filtered
+# frame after frame (:737-801) and the cube window shifts because the sensor really is 375 m from where it started (:323-507).
+# Stored: every frame's odometry and refined pose, map<-odom transform, window centre and class totals; every CHECK frames (and the last) the cube
+# ids / populations and the sha256 of each class's points in cube order, the registered cloud's, and the sweep's own sha256.
+LONG_CASES = [("reflong_hdl64_c512_seed51", "HDL-64", 300, 51, {"columns": 512, "travel": True, "step": 1.6}, 0.4, 0.8, 25)]
+
+
+def main_long():
+    import json, time
+    assert ref_py.build()
+    for tag, name, frames, seed, kw, line_res, plane_res, check in LONG_CASES:
+        t0 = time.time()
+        scans, R, t, model = syn.make_sequence(name, frames, seed=seed, **kw)
+        xs = [s.numpy() for s in scans]
+        t1 = time.time()
+        reg = ref_py.scan_registration(xs, model.n_scans, model.min_range)
+        odo = ref_py.laser_odometry(reg)
+        t2 = time.time()
+        fr = [dict(q_w=o["q_w"], t_w=o["t_w"], corner_last=o["corner_last"], surf_last=o["surf_last"], cloud=r["cloud"]) for o, r in zip(odo, reg)]
+        mp = ref_py.laser_mapping(fr, line_res, plane_res)
+        t3 = time.time()
+        # The reference's own sensitivity, as the yardstick for any free-running comparison over this horizon: the same three translation units
+        # on the same sweeps with ONE coordinate of one point in a hundred moved by ONE ulp (a different last bit of the sensor driver's float
+        # conversion).  Feature selection and every threshold of the pipeline are discrete decisions on those bits, so the two runs of the
+        # reference part ways at once and differ by centimetres after 300 frames.
+        ys = [x.copy() for x in xs]
+        for k in range(frames):
+            ys[k][k % 100::100, 0] = np.nextafter(ys[k][k % 100::100, 0], np.float32(1e9))
+        reg_u = ref_py.scan_registration(ys, model.n_scans, model.min_range)
+        odo_u = ref_py.laser_odometry(reg_u)
+        mp_u = ref_py.laser_mapping([dict(q_w=o["q_w"], t_w=o["t_w"], corner_last=o["corner_last"], surf_last=o["surf_last"], cloud=r["cloud"])
+                                     for o, r in zip(odo_u, reg_u)], line_res, plane_res, dump_map=False)
+        out = {"sensor": name, "seed": seed, "kwargs": json.dumps(kw), "n_scans": model.n_scans, "min_range": model.min_range, "frames": frames,
+               "max_points": max(len(x) for x in xs), "line_res": line_res, "plane_res": plane_res, "check": check,
+               "ulp_t_w": np.stack([m["t_w"] for m in mp_u]), "ulp_q_w": np.stack([m["q_w"] for m in mp_u]),
+               "ulp_odom_t": np.stack([o["t_w"] for o in odo_u]), "ulp_odom_q": np.stack([o["q_w"] for o in odo_u]),
+               "gt_R": R.numpy(), "gt_t": t.numpy(),
+               "odom_q": np.stack([f["q_w"] for f in fr]), "odom_t": np.stack([f["t_w"] for f in fr]),
+               "q_w": np.stack([m["q_w"] for m in mp]), "t_w": np.stack([m["t_w"] for m in mp]),
+               "q_wmap_wodom": np.stack([m["q_wmap_wodom"] for m in mp]), "t_wmap_wodom": np.stack([m["t_wmap_wodom"] for m in mp]),
+               "cen": np.array([m["cen"] for m in mp], np.int32),
+               "corr": np.array([[o["corner_corr"], o["plane_corr"]] for o in odo], np.int32),
+               "scan_n": np.array([len(x) for x in xs], np.int32),
+               "map_total": np.array([[sum(len(v) for v in m["corner_map"].values()), sum(len(v) for v in m["surf_map"].values())] for m in mp], np.int32),
+               "map_cubes": np.array([[len(m["corner_map"]), len(m["surf_map"])] for m in mp], np.int32)}
+        for k in sorted(set(range(0, frames, check)) | {frames - 1}):
+            out[f"scan_sha{k}"] = sha(xs[k])
+            out[f"registered_sha{k}"], out[f"registered_n{k}"] = sha(mp[k]["registered"]), len(mp[k]["registered"])
+            for nm in ("corner_map", "surf_map"):
+                ids = sorted(mp[k][nm])
+                out[f"{nm}_ids{k}"] = np.array(ids, np.int32)
+                out[f"{nm}_cnt{k}"] = np.array([len(mp[k][nm][c]) for c in ids], np.int32)
+                out[f"{nm}_sha{k}"] = sha(np.concatenate([mp[k][nm][c] for c in ids]) if ids else np.zeros((0, 4), np.float32))
+        path = os.path.join(ROOT, "tests", "golden", tag + ".npz")
+        np.savez_compressed(path, **out)
+        err = np.linalg.norm(out["t_w"] - (R[0].numpy().T @ (t.numpy() - t[0].numpy()).T).T, axis=1)
+        print(path, os.path.getsize(path) // 1024, "KiB; render %.0f s, registration + odometry %.0f s, mapping %.0f s" % (t1 - t0, t2 - t1, t3 - t2))
+        du = np.linalg.norm(out["ulp_t_w"] - out["t_w"], axis=1)
+        print("  the reference against itself with 1 %% of the input points moved by one ulp: refined pose differs by %.2e m at frame 25, %.2e at 100, max %.2e; first frame beyond 1e-4 m: %d"
+              % (du[25], du[100], du.max(), int(np.argmax(du > 1e-4))))
+        print("  window centre first / last", out["cen"][0], out["cen"][-1], "first shift at frame", int(np.argmax((out["cen"] != out["cen"][0]).any(1))),
+              "; map totals last", out["map_total"][-1], "; refined-pose error vs ground truth: median %.3f m, last %.3f m" % (np.median(err), err[-1]))
+
+
 if __name__ == "__main__":
-    if "--full-mapping" in sys.argv:
+    if "--long" in sys.argv:
+        main_long()
+    elif "--full-mapping" in sys.argv:
         main_full_mapping()
     elif "--full" in sys.argv:
         main_full()
@@ -228,3 +296,4 @@ if __name__ == "__main__":
         main_distortion()
         main_full()
         main_full_mapping()
+        main_long()
