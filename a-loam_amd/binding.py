@@ -105,6 +105,7 @@ def lib():
         L.aloam_get_ring_ranges.argtypes = [vp, C.c_int, vp, vp]
         L.aloam_get_curvature.argtypes = [vp, C.c_int, vp, C.c_int]
         L.aloam_get_labels.argtypes = [vp, C.c_int, vp, C.c_int]
+        L.aloam_get_last_cloud_order.argtypes = [vp, C.c_int, vp]
         L.aloam_get_correspondences.argtypes = [vp, C.c_int, vp, C.c_int, ip, vp, vp, C.c_int, ip, vp]
         L.aloam_mapping_enable.argtypes = [vp, C.c_float, C.c_float, C.c_int]
         L.aloam_mapping_step.argtypes = [vp]
@@ -264,6 +265,11 @@ class Aloam:
         st = AloamOdomStats()
         self._check(lib().aloam_get_odom_stats(self.h, seq, C.byref(st)))
         return {k: list(getattr(st, k)) for k, _ in AloamOdomStats._fields_}
+
+    def last_cloud_order(self, seq=0):
+        v = np.zeros(2, np.int32)
+        self._check(lib().aloam_get_last_cloud_order(self.h, seq, _p(v)))
+        return int(v[0]), int(v[1])
 
     def correspondences(self, seq=0):
         cap_e, cap_p = self.n_scans * 12, self.n_scans * 24

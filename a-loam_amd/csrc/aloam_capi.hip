@@ -62,9 +62,8 @@ struct aloam_ctx {
   int* d_grid_start3[2] = {nullptr, nullptr}; int* d_grid_start2[2] = {nullptr, nullptr};
   float4* d_grid_sorted3c[2] = {nullptr, nullptr};   // coarse level of the 3-D grid
   int* d_grid_start3c[2] = {nullptr, nullptr};
-  int* d_grid_flags[2] = {nullptr, nullptr};
+  int* d_grid_flags[2] = {nullptr, nullptr}; int* d_grid_walk[2] = {nullptr, nullptr};
   int grid_H[2] = {4096, 16384};
-  bool grids_valid = false;          // the grids describe the current "last" clouds
   EdgeRec* d_edges = nullptr; PlaneRec* d_planes = nullptr;
   float4 *d_sel_sharp = nullptr, *d_sel_flat = nullptr;
   // scan-to-map refinement (allocated by aloam_mapping_enable)
@@ -191,7 +190,7 @@ OdomArgs odom_args(aloam_ctx* c) {
     a.grid_sorted3[k] = c->d_grid_sorted3[k]; a.grid_sorted2[k] = c->d_grid_sorted2[k]; a.grid_start3[k] = c->d_grid_start3[k];
     a.grid_sorted3c[k] = c->d_grid_sorted3c[k]; a.grid_start3c[k] = c->d_grid_start3c[k];
     a.grid_start2[k] = c->d_grid_start2[k];
-    a.grid_flags[k] = c->d_grid_flags[k];
+    a.grid_flags[k] = c->d_grid_flags[k]; a.grid_walk[k] = c->d_grid_walk[k];
   }
   a.grid_H_corner = c->grid_H[0]; a.grid_H_surf = c->grid_H[1];
   a.edges = c->d_edges; a.planes = c->d_planes;
@@ -346,6 +345,7 @@ int aloam_create_stages(const aloam_config* cfg, int stages, aloam_ctx** out) {
       if ((rc = dmalloc(c, &c->d_grid_sorted3c[k], B * per))) return rc;
       if ((rc = dmalloc(c, &c->d_grid_start3c[k], B * (c->grid_H[k] + 1)))) return rc;
       if ((rc = dmalloc(c, &c->d_grid_flags[k], B * 4))) return rc;
+      if ((rc = dmalloc(c, &c->d_grid_walk[k], B * 2 * (R + 8)))) return rc;
     }
     if ((rc = dmalloc(c, &c->d_edges, B * R * 12))) return rc;
     if ((rc = dmalloc(c, &c->d_planes, B * R * 24))) return rc;
@@ -375,7 +375,7 @@ void aloam_destroy(aloam_ctx* c) {
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes, c->d_sel_sharp, c->d_sel_flat,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
                   c->d_grid_start2[0], c->d_grid_start2[1],
-                  c->d_grid_flags[0], c->d_grid_flags[1], c->d_grid_sorted3c[0], c->d_grid_sorted3c[1],
+                  c->d_grid_flags[0], c->d_grid_flags[1], c->d_grid_walk[0], c->d_grid_walk[1], c->d_grid_sorted3c[0], c->d_grid_sorted3c[1],
                   c->d_grid_start3c[0], c->d_grid_start3c[1],
                   c->d_mapseq, c->d_cubes, c->d_pool[0], c->d_pool[1], c->d_maptab, c->d_stack[0], c->d_stack[1], c->d_stack_world[0], c->d_stack_world[1],
                   c->d_stack_cube[0], c->d_stack_cube[1], c->d_addcnt, c->d_cursor, c->d_mgrid_sorted[0], c->d_mgrid_sorted[1], c->d_mgrid_start[0],
@@ -761,6 +761,22 @@ int aloam_get_labels(aloam_ctx* c, int seq, int* out, int cap) {
   if (k > 0) HIP_TRY(c, hipMemcpy(tmp.data(), c->d_label + (size_t)seq * c->cap, k, hipMemcpyDeviceToHost));
   for (int i = 0; i < k; ++i) out[i] = tmp[i];
   return m.n_cloud;
+}
+
+// Which association kernels own the sequence's last clouds (k_build_grids_fused): per cloud 0 = ring-sorted keys (pair kernel), 1 = nearly
+// ring-sorted (pair kernel with the index-range walk window), 2 = not sorted (literal walks), -1 = keys / coordinates out of range (literal search).
+int aloam_get_last_cloud_order(aloam_ctx* c, int seq, int out[2]) {
+  DeviceScope device_scope(c);
+  int rc = check_seq(c, seq);
+  if (rc) return rc;
+  if (!c->d_grid_flags[0]) { c->err = "this context has no odometry stage"; return ALOAM_E_STATE; }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 2; ++k) {
+    int f[4];
+    HIP_TRY(c, hipMemcpy(f, c->d_grid_flags[k] + (size_t)seq * 4, sizeof(f), hipMemcpyDeviceToHost));
+    out[k] = f[0] ? -1 : f[1];
+  }
+  return ALOAM_OK;
 }
 
 int aloam_get_correspondences(aloam_ctx* c, int seq, float* edges, int cap_edges, int* n_edges, int* edge_query,

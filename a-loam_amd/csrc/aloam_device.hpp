@@ -89,8 +89,10 @@ struct OdomArgs {
   int* grid_start2[2];       // [B][H+1]
   float4* grid_sorted3c[2];  // coarse levels of the same two grids: they bound the search of far queries
   int* grid_start3c[2];      // [B][H+1]
-  int* grid_flags[2];        // [B][4]   flags[0] != 0: keys / coordinates out of range -> literal brute-force path; flags[1] != 0: not ring-sorted -> literal walks;
-                             //          flags[2] != 0: the coarse level holds 16-bit positions into the fine copy (k_build_grids_fused)
+  int* grid_flags[2];        // [B][4]   flags[0] != 0: keys / coordinates out of range -> literal brute-force path; flags[1]: 0 = ring-sorted, 1 = NEARLY ring-sorted
+                             //          (no key more than 2 below an earlier one: the reference's walks still visit one index range, grid_walk holds its ends),
+                             //          2 = not sorted -> literal walks; flags[2] != 0: the coarse level holds 16-bit positions into the fine copy (k_build_grids_fused)
+  int* grid_walk[2];         // [B][2][R + 8]   per ring key k: first index with key >= k, last index with key <= k (written for nearly-sorted clouds only)
   int grid_H_corner, grid_H_surf;   // buckets (power of two, multiple of 1024)
   float4* sel_sharp;         // [B][R*12]  features moved to the start of the sweep with the current pose (k_transform_queries)
   float4* sel_flat;          // [B][R*24]
@@ -105,7 +107,7 @@ struct OdomArgs {
 struct GridView {
   int H;
   float4 *sorted3, *sorted2, *sorted3c;
-  int *start3, *start2, *start3c, *flags;
+  int *start3, *start2, *start3c, *flags, *walk;
 };
 __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int which) {
   GridView g;
@@ -118,6 +120,7 @@ __device__ __forceinline__ GridView grid_view(const OdomArgs& a, int b, int whic
   g.sorted3c = a.grid_sorted3c[which] + b * per;
   g.start3c = a.grid_start3c[which] + (long long)b * (g.H + 1);
   g.flags = a.grid_flags[which] + b * 4;
+  g.walk = a.grid_walk[which] + (long long)b * 2 * (a.R + 8);
   return g;
 }
 

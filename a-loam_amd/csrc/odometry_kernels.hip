@@ -165,6 +165,44 @@ __device__ __forceinline__ unsigned hash3(int a, int b, int c) {
                                 // own 16-byte copy.  Measured on one box, same run: k_build_grids 1.42 -> 1.31 ms, k_associate[plane] 2.84 -> 3.25 ms
 #endif
 constexpr int kFusedMaxN = 65535, kFusedMaxH = 16384;
+constexpr int kWalkKeys = kMaxRings + 8;
+
+// Clouds whose ring keys are ALMOST ascending.  int(intensity) is the reference's ring id (src/laserOdometry.cpp:308,398), intensity = scanID + 0.1 relTime
+// (src/scanRegistration.cpp:239), and relTime is slightly negative for the points of a ring that lie before the azimuth of the sweep's FIRST point
+// (:211-214): as soon as that first ray had no return (any real sweep; every synthetic one with a range limit), a few points of ring r carry the key
+// r - 1 in the middle of ring r's stretch.  The reference's walks (:315-361, :410-455) go up from the closest point until a key exceeds closest + 2 and
+// down until one falls below closest - 2.  If no key is more than 2 below an EARLIER key, the first key >= c + 3 above the closest point is the first
+// one in the whole cloud and the last key <= c - 3 below it the last one in the whole cloud, so the walks still visit ONE index range, whose ends
+// depend on c alone: first[c + 3] and last[c - 3], two tables of R + 8 entries.  The pair kernel then takes "index inside the range" for "key within
+// +-2" and the direction-dependent class rules for "same ring / other ring" (consider2<.., true>), exactly; only clouds with deeper descents
+// (possible through aloam_set_last) keep the literal one-query walks.   s_flag[1]: 1 = nearly sorted (tables written), 2 = not.
+__device__ __forceinline__ void walk_tables(const float4* __restrict__ pts, int n, int R, int* __restrict__ walk, int* s_walk, int* s_flag, int tid) {
+  const int S = R + 8, lane = tid & 63;
+  int* s_first = s_walk;
+  int* s_last = s_walk + kWalkKeys;
+  for (int k = tid; k < kWalkKeys; k += 1024) { s_first[k] = 0x7fffffff; s_last[k] = -1; }
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {              // consecutive lanes hold consecutive points: only the ends of a run of equal keys touch the LDS
+    const int i = base + tid;
+    const int key = i < n ? (int)pts[i].w : -1;
+    const int prev = __shfl_up(key, 1, 64), next = __shfl_down(key, 1, 64);
+    if (key >= 0 && key < S) {
+      if (lane == 0 || prev != key) atomicMin(&s_first[key], i);
+      if (lane == 63 || next != key) atomicMax(&s_last[key], i);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = n;
+    for (int k = S - 1; k >= 0; --k) { run = min(run, s_first[k]); s_first[k] = run; walk[k] = run; }               // first index with key >= k (n: none)
+    run = -1;
+    for (int k = 0; k < S; ++k) { run = max(run, s_last[k]); s_last[k] = run; walk[S + k] = run; }                  // last index with key <= k (-1: none)
+    bool nearly = true;
+    for (int k = 3; k < S; ++k) nearly = nearly && s_last[k - 3] < s_first[k];                                      // no key <= k - 3 after a key >= k
+    s_flag[1] = nearly ? 1 : 2;
+  }
+  __syncthreads();
+}
 __host__ __device__ __forceinline__ bool fused_takes(int n, int H) { return n <= kFusedMaxN && H <= kFusedMaxH; }
 
 #ifdef ALOAM_BG_TIMING   // variant builds: one surf workgroup prints the duration of its phases (device timer, 10 ns units)
@@ -186,6 +224,7 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
   unsigned* tab = reinterpret_cast<unsigned*>(lds);     // [3][H / 2]: bucket h of table t lives in half (h & 1) of word t * H / 2 + h / 2
   int* s_part = lds + 3 * (H / 2);                      // [3][16] wave totals of the scans
   int* s_flag = s_part + 48;                            // bad, unsorted
+  int* s_walk = s_flag + 8;                             // [2][kWalkKeys] first / last index of every ring key (clouds with a descending key only)
   int* const starts[3] = {g.start3, g.start3c, g.start2};
   // ALOAM_COARSE_VIA builds only: the coarse level gets no 16-byte copy of its own, an entry is the 16-bit POSITION of the point in
   // the fine copy (same buffer, read as unsigned short; flags[2] tells k_associate).  Both that and the ring grid as positions were
@@ -237,6 +276,7 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
   }
   __syncthreads();
   BG_T(1);
+  if (s_flag[1] && !s_flag[0]) walk_tables(pts, n, a.R, g.walk, s_walk, s_flag, tid);    // some key is lower than its predecessor's: nearly sorted or not at all?
   if (tid < 3) g.flags[tid] = tid == 2 ? ALOAM_COARSE_VIA : s_flag[tid];
   // ---- exclusive scans of the three tables: every thread owns H / 1024 consecutive buckets (= H / 2048 words) of each
   {
@@ -376,7 +416,7 @@ __global__ __launch_bounds__(1024, ALOAM_BG_WAVES) void k_build_grids(OdomArgs a
       if (unsorted) atomicOr(&s_flag[1], 1);
     }
     __syncthreads();
-    if (pass == 0 && tid < 3) g.flags[tid] = tid == 2 ? 0 : s_flag[tid];
+    if (pass == 0 && tid < 3) g.flags[tid] = tid == 2 ? 0 : (tid == 1 ? 2 * s_flag[1] : s_flag[0]);   // (clouds beyond the fused build: any descending key -> literal walks)
     // exclusive scan of cnt[H]: per-thread run of H/1024 consecutive buckets + scan of the 1024 partial sums
     const int per = g.H / 1024;
     int local = 0;
@@ -972,12 +1012,20 @@ __device__ __forceinline__ void take_min(unsigned long long& t, unsigned long lo
 // Second / third neighbour of the window form (ring-sorted clouds: j > closest implies key >= cid, so "key <= cid on the way up, key >= cid on
 // the way down" (:416-426, :444-454) is key == cid, and the corner class's "key > cid up, key < cid down" (:315-316, :341-342) is key != cid).
 // Visit order: upward from closest + 1, then downward from closest - 1; first strictly smaller distance wins = lexicographic (distance, order).
-template <bool PLANE>
-__device__ __forceinline__ void consider2(float d, int j, int key, int closest, int cid, unsigned long long& t2, unsigned long long& t3) {
+// NEARLY (clouds whose keys are almost ascending, walk_tables above): the walks visit the index range (lo, hi); on the way up a key <= cid is "same
+// ring" for the planar class and skipped by the corner class, on the way down a key >= cid (:315-316,341-342 / :416-426,444-454) - the literal rules.
+template <bool PLANE, bool NEARLY = false>
+__device__ __forceinline__ void consider2(float d, int j, int key, int closest, int cid, unsigned long long& t2, unsigned long long& t3, int lo = 0, int hi = 0) {
   const int t = j - closest, nt = closest - j;
   const unsigned seq = (unsigned)(t > nt ? t : nt) | ((unsigned)t & 0x80000000u);   // up: j - closest; down: 2^31 + closest - j
-  const bool ok = j != closest && (unsigned)(key - cid + 2) <= 4u && d < 25.0f;     // (double)d < 25.0 (:305,393) is the same test: 25 is an f32 number
-  const bool own = key == cid;
+  bool ok, own;
+  if (NEARLY) {
+    ok = j != closest && j > lo && j < hi && d < 25.0f;
+    own = t > 0 ? key <= cid : key >= cid;
+  } else {
+    ok = j != closest && (unsigned)(key - cid + 2) <= 4u && d < 25.0f;               // (double)d < 25.0 (:305,393) is the same test: 25 is an f32 number
+    own = key == cid;
+  }
   // a candidate outside its class enters the minimum with distance word ~0: "nothing found" is a key whose HIGH word is ~0 (none() below)
   const unsigned db = __float_as_uint(d);
   if (PLANE) {
@@ -1079,9 +1127,9 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
 #ifndef ALOAM_RING_OWN_CELL_FIRST
 #define ALOAM_RING_OWN_CELL_FIRST PLANE   // A/B builds: 0 = the 3x3 block in one stage, 1 = own cell first for both classes
 #endif
-template <bool PLANE, int kRows, bool HALVES>
+template <bool PLANE, int kRows, bool HALVES, bool NEARLY>
 __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index, float sx, float sy, float sz, int closest, int cid, bool want2, bool want3,
-                                          unsigned long long& best2, unsigned long long& best3, int lane, int last4, int* lds) {
+                                          unsigned long long& best2, unsigned long long& best3, int lane, int last4, int* lds, int lo, int hi) {
   constexpr bool kOwnFirst = ALOAM_RING_OWN_CELL_FIRST;
   constexpr int W = HALVES ? 32 : 64;
   const int l = lane & (W - 1);
@@ -1098,7 +1146,8 @@ __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index
     ALOAM_STAT(PLANE ? 1 : 0, 24 + stage, 1);
     // look-ups: lane = slot * cells + cell; slots 0..3 = the rings cid -1, +1, -2, +2, slot 4 = cid (planar class).  Stage 1 without the own-cell
     // stage has 9 cells: the own cell is looked up by the lanes behind the 8 x slots block
-    const bool wo = PLANE ? want3 : want2, ws = PLANE && want2;          // other rings wanted / own ring wanted
+    // other rings wanted / own ring wanted (nearly-sorted clouds: a "same ring" neighbour may carry a neighbouring key, so either wish looks everywhere)
+    const bool wo = PLANE ? (NEARLY ? want2 || want3 : want3) : want2, ws = PLANE && (NEARLY ? want2 || want3 : want2);
     const int lc = stage == 0 ? 0 : stage == 1 ? 3 : 4, ncell = 1 << lc, nslot = PLANE ? 5 : 4;
     const int n_look = ncell * nslot + (stage == 1 && !kOwnFirst ? nslot : 0);
     ALOAM_PHASE("ring_lookup");
@@ -1126,7 +1175,7 @@ __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index
       ALOAM_PHASE("ring_sweep");
       sweep2<HALVES, kRows>(g.sorted2, last_index, s0, cnt, lane, last4, lds, [&](const float4& p, int, bool) {
         const unsigned wb = __float_as_uint(p.w);
-        consider2<PLANE>(dist_to(p, sxy, sz), (int)(wb & kIdxMask), (int)(wb >> 20) - 1, closest, cid, t2, t3);
+        consider2<PLANE, NEARLY>(dist_to(p, sxy, sz), (int)(wb & kIdxMask), (int)(wb >> 20) - 1, closest, cid, t2, t3, lo, hi);
       }, nullptr, nullptr, PLANE ? 1 : 0, 8 + 4 * stage);
     }
     ALOAM_PHASE("ring_mins");
@@ -1150,7 +1199,7 @@ __device__ __forceinline__ unsigned long long read_u64(unsigned long long v, int
 }
 __device__ __forceinline__ float read_f32(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
-template <bool PLANE, int kRows, bool PAIRED_TAILS>
+template <bool PLANE, int kRows, bool PAIRED_TAILS, bool NEARLY>
 __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0, int nq, int nt, const GridView& g, int lane, int* lds) {
   constexpr int kRows1 = (kRows + 1) / 2;                                    // rows of 64 of the one-query tails
   const int l = lane & 31, hsel = lane >> 5, last4 = (lane | 31) << 2;
@@ -1223,6 +1272,12 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
   const int closest = (int)((unsigned)nn >> 12);
   const int cid = (int)((unsigned)nn & 0xfffu) - 1;                          // closestPointScanID (:308,398)
   unsigned long long best2 = ~0ull, best3 = ~0ull;
+  int wlo = -1, whi = nt;                                                    // nearly-sorted clouds: the index range the reference's walks visit
+  if (NEARLY && has1) {
+    const int S = a.R + 8, c = min(max(cid, 0), a.R);
+    whi = g.walk[c + 3];
+    wlo = c >= 3 ? g.walk[S + c - 3] : -1;
+  }
   ALOAM_STAT(PLANE ? 1 : 0, 0, 1); ALOAM_STAT(PLANE ? 1 : 0, 1, (int)((__ballot(qact) & 1) + ((__ballot(qact) >> 32) & 1))); ALOAM_STAT(PLANE ? 1 : 0, 2, (int)((__ballot(has1) & 1) + ((__ballot(has1) >> 32) & 1)));
   ALOAM_STAT(PLANE ? 1 : 0, 3, (int)((__ballot(has1 && kept.ok) & 1) + ((__ballot(has1 && kept.ok) >> 32) & 1)));
   if (__ballot(has1)) {
@@ -1234,7 +1289,7 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
       for (int u = 0; u < kRows; ++u) {
         if (u >= kept_rows) continue;
         const unsigned lo = (unsigned)kept.k[u];
-        consider2<PLANE>(__uint_as_float((unsigned)(kept.k[u] >> 32)), (int)(lo >> 12), (int)(lo & 0xfffu) - 1, closest, cid, t2, t3);
+        consider2<PLANE, NEARLY>(__uint_as_float((unsigned)(kept.k[u] >> 32)), (int)(lo >> 12), (int)(lo & 0xfffu) - 1, closest, cid, t2, t3, wlo, whi);
       }
       const bool use = has1 && kept.ok;
       best2 = half_min_packed(use ? t2 : ~0ull, last4);
@@ -1246,7 +1301,7 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
     ALOAM_PHASE("ring_tail");
     const unsigned long long w2 = __ballot(want2), w3 = __ballot(want3);
     const bool r0 = (w2 | w3) & 1ull, r1 = ((w2 | w3) >> 32) & 1ull;
-    if (PAIRED_TAILS && r0 && r1) ring_grid<PLANE, kRows1, true>(g, last_index, sel.x, sel.y, sel.z, closest, cid, want2, want3, best2, best3, lane, last4, lds);
+    if (PAIRED_TAILS && r0 && r1) ring_grid<PLANE, kRows1, true, NEARLY>(g, last_index, sel.x, sel.y, sel.z, closest, cid, want2, want3, best2, best3, lane, last4, lds, wlo, whi);
     else {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
@@ -1256,8 +1311,8 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
         continue;                                                              // timing experiments only: wrong results
 #endif
         unsigned long long r2 = read_u64(best2, 32 * q), r3 = read_u64(best3, 32 * q);
-        ring_grid<PLANE, kRows1, false>(g, last_index, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), __builtin_amdgcn_readlane(closest, 32 * q),
-                                        __builtin_amdgcn_readlane(cid, 32 * q), q2, q3, r2, r3, lane, 0, lds);
+        ring_grid<PLANE, kRows1, false, NEARLY>(g, last_index, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), __builtin_amdgcn_readlane(closest, 32 * q),
+                                                __builtin_amdgcn_readlane(cid, 32 * q), q2, q3, r2, r3, lane, 0, lds, __builtin_amdgcn_readlane(wlo, 32 * q), __builtin_amdgcn_readlane(whi, 32 * q));
         if (hsel == q) { best2 = r2; best3 = r3; }
       }
     }
@@ -1306,9 +1361,31 @@ __global__ __launch_bounds__(64) ALOAM_PAIR_OCC void k_associate_pair(OdomArgs a
   if (qi0 >= nq) return;
   const GridView g = grid_view(a, b, PLANE ? 1 : 0);
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
-  if (g.flags[0] != 0 || g.flags[1] != 0 || nt <= 0) return;                 // k_associate_flagged owns this sequence
+  if (g.flags[0] != 0 || g.flags[1] != 0 || nt <= 0) return;                 // k_associate_nearly / k_associate_flagged own this sequence
   // (128-ring sensors: the paired tails would take the planar class from 79 to 85 registers, six waves per SIMD to five, for their ~1 %)
-  associate_pair<PLANE, kRows, ALOAM_PAIR_TAILS && !WIDE>(a, b, qi0, nq, nt, g, lane, lds);
+  associate_pair<PLANE, kRows, ALOAM_PAIR_TAILS && !WIDE, false>(a, b, qi0, nq, nt, g, lane, lds);
+}
+
+// Sequences whose last cloud is NEARLY ring-sorted (flags[1] == 1, walk_tables above: a sweep whose first ray had no return - a handful of
+// sequences per step on range-limited data, most sweeps of a real sensor): the same pair code with the index-range form of the walk window.  A
+// kernel of its own so that its three extra registers do not cost the ring-sorted majority a wave per SIMD (71 -> 74 / 62 -> 65 registers when the
+// two forms share a kernel); every wave takes kPairsPerWave pairs of its sequence in turn, so the launch is small enough to be free when nothing is flagged.
+constexpr int kPairsPerWave = 8;
+template <bool PLANE, bool WIDE>
+__global__ __launch_bounds__(64) void k_associate_nearly(OdomArgs a) {
+  constexpr int kRows = PairRows<PLANE, WIDE>::value;
+  __shared__ int lds[sweep2_lds_ints<kRows>()];
+  const int lane = threadIdx.x, b = blockIdx.y;
+  const GridView g = grid_view(a, b, PLANE ? 1 : 0);
+  if (g.flags[0] != 0 || g.flags[1] != 1) return;
+  const SeqMeta m = a.meta[b];
+  const int nq = PLANE ? m.n_flat : m.n_sharp, nt = PLANE ? m.n_surf_last : m.n_corner_last;
+  if (nt <= 0) return;
+  for (int k = 0; k < kPairsPerWave; ++k) {
+    const int qi0 = (blockIdx.x * kPairsPerWave + k) * 2;
+    if (qi0 >= nq) return;
+    associate_pair<PLANE, kRows, ALOAM_PAIR_TAILS && !WIDE, true>(a, b, qi0, nq, nt, g, lane, lds);
+  }
 }
 
 // Sequences the pair kernel leaves alone: clouds that are not ring-sorted or hold keys / coordinates outside the range the grids are
@@ -1322,7 +1399,7 @@ __global__ __launch_bounds__(256) void k_associate_flagged(OdomArgs a) {
   const SeqMeta m = a.meta[b];
   const GridView g = grid_view(a, b, PLANE ? 1 : 0);
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
-  if (!(g.flags[0] != 0 || g.flags[1] != 0 || nt <= 0)) return;
+  if (!(g.flags[0] != 0 || g.flags[1] == 2 || nt <= 0)) return;
   const int nq = PLANE ? m.n_flat : m.n_sharp;
   for (int qi = wave; qi < nq; qi += 4) associate_one<PLANE, DISTORT, WIDE>(a, b, qi, m, g, lane, rows[wave]);
 }
@@ -1463,7 +1540,7 @@ void launch_advance(SeqMeta* meta, int B, hipStream_t s) { hipLaunchKernelGGL(k_
 
 // -------------------------------------------------------------------------------------------------------
 size_t build_grids_lds_bytes(int H, int R) { return sizeof(int) * ((size_t)H + 1024 + 2 * (R + 8) + 4); }
-static size_t build_grids_fused_lds_bytes(int H) { return sizeof(int) * (3 * (size_t)(H / 2) + 48 + 8); }
+static size_t build_grids_fused_lds_bytes(int H) { return sizeof(int) * (3 * (size_t)(H / 2) + 48 + 8 + 2 * kWalkKeys); }
 // The surf grid needs > 64 KiB of dynamic LDS: the attribute belongs to the function ON the current device; aloam_create sets it
 // once per context (no process-global state).
 int prepare_build_grids(int H_surf) {
@@ -1500,6 +1577,14 @@ void launch_associate(const OdomArgs& a, bool plane, hipStream_t s) {
     } else {
       if (plane) hipLaunchKernelGGL((k_associate_pair<true, false>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
       else hipLaunchKernelGGL((k_associate_pair<false, false>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
+    }
+    const dim3 gridn((unsigned)((qcap / 2 + kPairsPerWave - 1) / kPairsPerWave), (unsigned)a.B);
+    if (wide) {
+      if (plane) hipLaunchKernelGGL((k_associate_nearly<true, true>), gridn, block, 0, s, a);
+      else hipLaunchKernelGGL((k_associate_nearly<false, true>), gridn, block, 0, s, a);
+    } else {
+      if (plane) hipLaunchKernelGGL((k_associate_nearly<true, false>), gridn, block, 0, s, a);
+      else hipLaunchKernelGGL((k_associate_nearly<false, false>), gridn, block, 0, s, a);
     }
     if (wide) {
       if (plane) hipLaunchKernelGGL((k_associate_flagged<true, false, true>), gridf, blockf, 0, s, a);

@@ -87,13 +87,17 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=6, help="stored sweeps per sequence (replayed ping-pong)")
     ap.add_argument("--sensor", default="HDL-64", help="headline workload sensor (HDL-64 = BASELINE configs[1]; ROWS128 = configs[3])")
     ap.add_argument("--mapping", action="store_true", help="headline workload = BASELINE configs[2]: scan-to-map refinement after every sweep")
-    ap.add_argument("--map-pool", type=int, default=262144, help="device map capacity per sequence and class (points)")
+    ap.add_argument("--map-pool", type=int, default=262144, help="device map capacity per sequence and class the contexts START with (points; the pools double as the maps grow)")
+    ap.add_argument("--map-batch", type=int, default=256, help="sequences per GPU of the configs[2] workload (travelling sensor, --map-frames distinct sweeps each)")
+    ap.add_argument("--map-frames", type=int, default=100)
+    ap.add_argument("--map-warmup", type=int, default=80, help="untimed steps of the configs[2] workload: 125 m of travel, after which the submap is stationary")
     ap.add_argument("--contexts", type=int, default=1, help="split the batch over this many contexts (= HIP streams) on the same GPU")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of each CPU baseline leg (one thread; one process per core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip host-input rate, configs[2]/[3] sub-workloads and latency")
     ap.add_argument("--host-input", action="store_true", help="(kept for compatibility: the host-fed rate is part of the default line)")
     ap.add_argument("--latency-sweeps", type=int, default=120)
+    ap.add_argument("--travel", action="store_true", help="odometry-only workload on the travelling drive (the configs[2] input: 1.6 m per sweep down a street, 120 m range) instead of laps of the 30 m circle; --frames distinct sweeps per sequence")
     ap.add_argument("--rough", action="store_true", help="KITTI-shaped irregular sweeps (random no-returns, ragged rings, noisy sectors, repeated returns) instead of the clean synthetic ones")
     return ap.parse_args()
 
@@ -170,6 +174,62 @@ class Workload:
         m = self.model
         return f"synthetic {self.sensor} {m.n_scans}x{m.columns} ({self.NP} pts/sweep{', rough: dropouts / ragged rings / repeated returns' if self.rough else ''}), " + (
             "odometry + laserMapping scan-to-map refinement every sweep" if mapping else "odometry only (scan registration + scan-to-scan odometry, no laserMapping)")
+
+
+class TravelWorkload(Workload):
+    """BASELINE.json configs[2] at steady-state map depth: every sequence DRIVES (a-loam_amd/synthetic.py `travel`: 1.6 m per sweep down a street, never
+    returning, 120 m sensor range), T distinct sweeps each, so that after the warm-up the submap the scan-to-map search runs on is the stationary one
+    of a moving sensor (everything mapped within the 5 x 5 x 3 cube window, reference src/laserMapping.cpp:509-539) instead of what six sweeps leave
+    behind.  `distinct` different drives are rendered and replicated over the batch (identical work per replica, separate memory)."""
+
+    def __init__(self, syn, torch, B, T, rank, dev, distinct=32, step=1.6):
+        self.sensor, self.B, self.T, self.rough = "HDL-64", B, T, False
+        self.model = syn.sensor_model("HDL-64", device=dev)
+        self.NP = self.model.dirs.shape[0]
+        t0 = time.time()
+        distinct = min(distinct, B)
+        assert B % distinct == 0
+        self.data = torch.zeros((B, T, self.NP, 4), dtype=torch.float32, device=dev)
+        self.counts = np.zeros((B, T), np.int32)
+        self.gt = {}
+        for b in range(distinct):
+            gseq = rank * distinct + b
+            world = syn.make_street_world(300 + gseq % 8).to(dev)
+            R, tt = syn.trajectory_travel(T, step=step, seed=gseq)
+            gen = torch.Generator(device=dev).manual_seed(9500 + gseq)
+            for k in range(T):
+                s = syn.render_scan(world, self.model, R[k], tt[k], 0.02, gen, max_range=syn.STREET_MAX_RANGE, cull=True)
+                self.counts[b, k] = s.shape[0]
+                self.data[b, k, : s.shape[0]] = s
+            if b < 4:
+                self.gt[b] = (R.numpy(), tt.numpy())
+        for r in range(1, B // distinct):
+            self.data[r * distinct:(r + 1) * distinct] = self.data[:distinct]
+            self.counts[r * distinct:(r + 1) * distinct] = self.counts[:distinct]
+        torch.cuda.synchronize()
+        self.gen_s = time.time() - t0
+        self.seq_stride = T * self.NP * 16
+        self.distinct, self.step = distinct, step
+
+    def describe(self, mapping):
+        m = self.model
+        return (f"synthetic {self.sensor} {m.n_scans}x{m.columns} ({self.NP} pts/sweep), sensor TRAVELLING {self.step} m per sweep down a street ({self.T} distinct sweeps per "
+                f"sequence, {self.distinct} distinct drives replicated over the batch), " + ("odometry + laserMapping scan-to-map refinement every sweep at steady-state submap depth"
+                                                                                             if mapping else "odometry only (scan registration + scan-to-scan odometry, no laserMapping)"))
+
+
+def map_state(cx, n_seq=4):
+    """What the scan-to-map search of the last step ran on (mean over a few sequences) and the state of the pools."""
+    infos = [cx.map_info(b) for b in range(min(n_seq, cx.batch))]
+    out = {k: int(round(float(np.mean([i[k] for i in infos])))) for k in ("frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack", "corner_num1", "surf_num1")}
+    cnt = np.zeros(21 * 21 * 11, np.int32)
+    binding = importlib.import_module("a-loam_amd.binding")
+    tot = []
+    for cls in (0, 1):
+        binding.lib().aloam_map_cube_counts(cx.h, 0, cls, binding._p(cnt))
+        tot.append((int(cnt.sum()), int((cnt > 0).sum())))
+    out.update({"map_points_corner": tot[0][0], "map_points_surf": tot[1][0], "occupied_cubes_corner": tot[0][1], "occupied_cubes_surf": tot[1][1], "pool": cx.map_pool_info()})
+    return out
 
 
 def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping, repeat_to_s=0.0, repeats_out=None):
@@ -574,7 +634,15 @@ def main():
 
     B, T = args.batch, args.frames
     free0, total_hbm = torch.cuda.mem_get_info(dev)
-    wl = Workload(syn, torch, args.sensor, B, T, rank, dev, rough=args.rough)
+    if args.mapping:        # configs[2] as the workload of this run (rocprofv3 / counter passes): the travelling sensor at steady-state map depth
+        assert args.sensor == "HDL-64"
+        B, T, args.warmup = args.map_batch, args.map_frames, max(args.warmup, args.map_warmup)
+        wl = TravelWorkload(syn, torch, B, T, rank, dev)
+    elif args.travel:
+        assert args.sensor == "HDL-64"
+        wl = TravelWorkload(syn, torch, B, T, rank, dev)
+    else:
+        wl = Workload(syn, torch, args.sensor, B, T, rank, dev, rough=args.rough)
     NC = max(1, args.contexts)
     assert B % NC == 0, "--batch must be a multiple of --contexts"
     ctxs = [wl.ctx(binding, B // NC, local_rank) for _ in range(NC)]
@@ -585,6 +653,7 @@ def main():
     # (not under --no-extras: that is what the rocprofv3 / counter passes and the A/B scripts run, and they want exactly W + K steps)
     elapsed, prof = timed_resident(torch, dist, world, ctxs, wl, args.steps, args.warmup, args.mapping, repeat_to_s=0.0 if args.no_extras else args.repeat_to_seconds, repeats_out=more)
     bscan = survey_b_scan(ctxs[0], wl)
+    mstate = map_state(ctxs[0]) if args.mapping else None
     free1, _ = torch.cuda.mem_get_info(dev)                # inputs + contexts of THIS rank (of every rank that shares the device under the test hook)
     try:
         import psutil
@@ -604,6 +673,8 @@ def main():
            "timed_region_s": round(elapsed, 3), "library_sha256": lib_sha256(),
            "memory": {"hbm_used_bytes": int(free0 - free1), "hbm_bytes_per_sequence": int((free0 - free1) / max(1, B)), "hbm_total_bytes": int(total_hbm),
                       "host_rss_bytes": rss, "host_ram_bytes": host_ram, "input_bytes": int(B * T * wl.NP * 16)}}
+    if mstate is not None:
+        out["map_state"] = mstate
     if more:     # spread of identical K-step blocks timed right after the contract block (which alone is `value` / `ms_per_step`)
         blocks = [elapsed] + more
         ms = sorted(1e3 * x / args.steps for x in blocks)
@@ -658,7 +729,23 @@ def main():
             "latency": lat_map}}
         if acc_map is not None:
             out["workloads"]["configs[2] odometry + laserMapping"]["accuracy"] = acc_map
+        out["workloads"]["configs[2] odometry + laserMapping"]["note"] = "the round-5 workload (six sweeps on a 30 m circle, ping-pong): a SHALLOW submap; kept for comparison with earlier rounds"
         del wl
+        torch.cuda.empty_cache()
+        # ---- the same at steady-state map depth: a travelling sensor, 100 distinct sweeps per sequence, submap stationary after the warm-up
+        Bt = args.map_batch
+        wlt = TravelWorkload(syn, torch, Bt, args.map_frames, rank, dev)
+        cx = wlt.ctx(binding, Bt, local_rank)
+        cx.mapping_enable(0.4, 0.8, args.map_pool)
+        steps_t = max(steps2, 60)
+        elt, proft = timed_resident(torch, dist, 1, [cx], wlt, steps_t, args.map_warmup, True)
+        out["workloads"]["configs[2] odometry + laserMapping, steady-state map depth"] = {
+            "workload": wlt.describe(True), "value": round(Bt * steps_t / elt, 2), "unit": "scans/s", "ms_per_step": round(1e3 * elt / steps_t, 4),
+            "steps": steps_t, "warmup": args.map_warmup, "sequences_per_gpu": Bt, "map_pool_points_at_start": args.map_pool,
+            "roofline": roofline_of(proft, steps_t, Bt, "HDL-64", True), "map_state": map_state(cx), "input_generation_s": round(wlt.gen_s, 2),
+            "ms_per_1024_sequences": round(1e3 * elt / steps_t * 1024 / Bt, 3)}
+        cx.close()
+        del wlt
         torch.cuda.empty_cache()
         # ---- BASELINE.json configs[3]: 128 rings x 2048 columns stress (ring index from the 4th float)
         T3 = min(T, 4)

@@ -176,6 +176,13 @@ int aloam_get_labels(aloam_ctx* ctx, int seq, int* out, int cap);               
 int aloam_get_correspondences(aloam_ctx* ctx, int seq, float* edges, int cap_edges, int* n_edges, int* edge_query,
                               float* planes, int cap_planes, int* n_planes, int* plane_query);
 
+/* How the ring ids of the clouds the last aloam_odometry_step searched (laserCloudCornerLast, laserCloudSurfLast of that step) are ordered, as
+ * found when their kd-tree stand-ins were built (src/laserOdometry.cpp:567-568): 0 = int(intensity) never decreases with the index; 1 = it decreases, but never by more than 2 below an earlier
+ * value (sweeps whose first ray had no return: relTime < 0 for the points before it, src/scanRegistration.cpp:211-214,239) - the reference's
+ * neighbour walks (src/laserOdometry.cpp:315-361,410-455) then still visit one index range and run on the fast path; 2 = neither (literal walks);
+ * -1 = ring ids / coordinates outside the range the grids are exact for (literal search). */
+int aloam_get_last_cloud_order(aloam_ctx* ctx, int seq, int out[2]);
+
 /* ---- per-kernel timing (hipEvents on the context's stream), for bench.py's roofline object ----------------- */
 int aloam_profile_enable(aloam_ctx* ctx, int on);
 int aloam_profile_kernel_count(void);

@@ -530,3 +530,87 @@ def test_pair_kernel_search_model_equals_the_walk_until_break_definition(plane, 
             got = model_query_pair(sel, g3, g3c, g2, plane, 6 if plane else 4, rng, own_first)
             want = reference_query(sel, pts, keys, plane)
             assert got == want, (plane, cell3, H, seed, trial, qi, sel, got, want)
+
+
+# ---- nearly ring-sorted clouds (round 6): the index-range form of the walk window (odometry_kernels.hip walk_tables / consider2<.., true>) ----------------
+def _literal_walks(keys, d, closest, plane):
+    """reference src/laserOdometry.cpp:315-361 (corner) / :410-455 (plane), on a cloud whose ring ids are `keys` and whose squared distances to the query are `d`."""
+    c, n = keys[closest], len(keys)
+    if not plane:
+        m, ind = 25.0, -1
+        for j in range(closest + 1, n):
+            if keys[j] <= c:
+                continue
+            if keys[j] > c + 2.5:
+                break
+            if d[j] < m:
+                m, ind = d[j], j
+        for j in range(closest - 1, -1, -1):
+            if keys[j] >= c:
+                continue
+            if keys[j] < c - 2.5:
+                break
+            if d[j] < m:
+                m, ind = d[j], j
+        return ind, -1
+    m2 = m3 = 25.0
+    i2 = i3 = -1
+    for j in range(closest + 1, n):
+        if keys[j] > c + 2.5:
+            break
+        if keys[j] <= c and d[j] < m2:
+            m2, i2 = d[j], j
+        elif keys[j] > c and d[j] < m3:
+            m3, i3 = d[j], j
+    for j in range(closest - 1, -1, -1):
+        if keys[j] < c - 2.5:
+            break
+        if keys[j] >= c and d[j] < m2:
+            m2, i2 = d[j], j
+        elif keys[j] < c and d[j] < m3:
+            m3, i3 = d[j], j
+    return i2, i3
+
+
+def _range_form(keys, d, closest, plane, R):
+    """What k_associate_nearly computes: candidates = indices inside (last[c - 3], first[c + 3]), class by direction and key, minimum of (distance, visit order)."""
+    n, S, c = len(keys), R + 8, keys[closest]
+    first = [next((i for i in range(n) if keys[i] >= k), n) for k in range(S)]
+    last = [next((i for i in range(n - 1, -1, -1) if keys[i] <= k), -1) for k in range(S)]
+    assert all(last[k - 3] < first[k] for k in range(3, S)), "not a nearly ring-sorted cloud (flags[1] would be 2)"
+    hi, lo = first[c + 3], (last[c - 3] if c >= 3 else -1)
+    best = {2: (np.inf, 0, -1), 3: (np.inf, 0, -1)}
+    for j in range(n):
+        if j == closest or not (lo < j < hi) or not d[j] < 25.0:
+            continue
+        t = j - closest
+        seq = t if t > 0 else (1 << 31) - t
+        own = keys[j] <= c if t > 0 else keys[j] >= c
+        cls = (2 if own else 3) if plane else (None if own else 2)
+        if cls is not None and (d[j], seq) < best[cls][:2]:
+            best[cls] = (d[j], seq, j)
+    return best[2][2], best[3][2]
+
+
+def test_index_range_form_of_the_walk_window_on_nearly_ring_sorted_clouds():
+    """A sweep whose first ray had no return carries ring ids one too low in the middle of every ring's stretch (negative relTime, reference
+    src/scanRegistration.cpp:211-214,239).  As long as no id lies more than 2 below an earlier one, the reference's walks visit exactly the index range
+    (last index with id <= c - 3, first index with id >= c + 3), and the neighbours are the (distance, visit order) minima of that range under the
+    direction-dependent class rules - including exact distance ties, ids two too low, empty rings and queries at either end of the cloud."""
+    rng = np.random.default_rng(0)
+    checked = 0
+    for _ in range(2500):
+        R = int(rng.integers(6, 20))
+        keys = []
+        for r in range(R):
+            for _k in range(int(rng.integers(0, 12))):
+                keys.append(max(0, r - (int(rng.integers(1, 3)) if rng.random() < 0.25 else 0)))
+        keys = np.array(keys, int)
+        if len(keys) < 3 or (np.maximum.accumulate(keys) - keys).max() > 2:
+            continue
+        d = rng.choice([1.0, 2.0, 3.0, 4.0, 30.0, 0.5], size=len(keys)) + rng.integers(0, 3, len(keys))      # few distinct values: ties everywhere
+        closest = int(rng.integers(0, len(keys)))
+        for plane in (False, True):
+            assert _literal_walks(keys, d, closest, plane) == _range_form(keys, d, closest, plane, R), (keys.tolist(), d.tolist(), closest, plane)
+            checked += 1
+    assert checked > 3000

@@ -74,6 +74,48 @@ def test_free_running_sequence_matches_oracle(O, binding, sequence, name, frames
     gpu.close()
 
 
+@pytest.mark.parametrize("name,kw,cut", [("HDL-64", {"columns": 512}, 40), ("HDL-64", {}, 150)])
+def test_sweeps_whose_first_ray_has_no_return(O, binding, sequence, name, kw, cut):
+    """relTime is measured from the azimuth of the sweep's FIRST point (reference src/scanRegistration.cpp:141,211-214,239).  When the first rays of
+    the first ring return nothing - any range-limited or real sweep - the points of the other rings that lie before that azimuth get a slightly
+    NEGATIVE relTime, intensity = scanID - eps, and int(intensity) = scanID - 1: the reference's ring id of a few points in the middle of every
+    ring's stretch is one too low, the last clouds are no longer ring-sorted, and its neighbour walks (src/laserOdometry.cpp:315-361,410-455)
+    break where THOSE keys say.  The pair kernel handles such nearly-sorted clouds with the index-range form of the walk window
+    (k_associate_nearly): same correspondences as the oracle's literal walks, bit for bit, and the sequence stays on the fast path."""
+    scans, R, t, model = sequence(name, 4, seed=7, **kw)
+    cut_scans = [x[cut:] for x in scans]                    # ring-major sweeps: the first `cut` rays of the first ring are gone
+    orc = O.Oracle(n_scans=model.n_scans, min_range=model.min_range)
+    gpu = _mk(binding, model, max_points=max(len(s) for s in scans) + 64)
+    orders, want = [], []
+
+    def order_of(cloud):
+        key = cloud[:, 3].astype(np.int32)
+        return 0 if not (np.diff(key) < 0).any() else (1 if (np.maximum.accumulate(key) - key).max() <= 2 else 2)
+
+    searched = None
+    for k, x in enumerate(cut_scans):
+        fo = orc.scan_register(x)
+        gpu.scan_register(x)
+        _assert_features_equal(fo, gpu.features(), (name, k))
+        if k > 0:
+            want.append(searched)
+        searched = (order_of(fo["less_sharp"]), order_of(fo["less_flat"]))     # what the NEXT step searches
+        po = orc.odometry_step()
+        gpu.odometry_step()
+        _assert_pose_close(po, gpu.pose(), (name, k))
+        so_, sg_ = orc.odom_stats(), gpu.odom_stats()
+        for sk in ("corner_corr", "plane_corr", "lm_iterations", "lm_successful", "termination"):
+            assert so_[sk] == sg_[sk], (name, k, sk, so_, sg_)
+        if k > 0:
+            eo, plo, eqo, pqo = orc.correspondences()
+            eg, plg, eqg, pqg = gpu.correspondences()
+            assert np.array_equal(eqo, eqg) and np.array_equal(pqo, pqg)
+            assert bits_equal(eo.astype(np.float32), eg) and bits_equal(plo.astype(np.float32), plg)
+            orders.append(gpu.last_cloud_order())
+    assert orders == want and sum(1 for o in want if o == (1, 1)) >= 2, (orders, want)   # nearly ring-sorted clouds stay with the pair kernel (order 1), not the literal walks (2)
+    gpu.close()
+
+
 def test_batched_sequences_are_independent_and_match_oracle(O, binding, sequence):
     """batch = 3 different sequences in one context == three single oracle runs (no cross-talk between sequences)."""
     seqs = [sequence("HDL-64", 3, seed=s, columns=1024) for s in (11, 12, 13)]

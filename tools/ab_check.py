@@ -30,7 +30,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-INPUTS = os.path.join(ROOT, "tools", "_ab_inputs.npz")
+INPUTS = os.environ.get("ALOAM_AB_INPUTS", os.path.join(ROOT, "tools", "_ab_inputs.npz"))   # ALOAM_AB_INPUTS: another input set, e.g. the travelling drive
 
 
 def opt(argv, name, default, cast=int):
@@ -41,8 +41,14 @@ def make_inputs(argv):
     syn = importlib.import_module("a-loam_amd.synthetic")
     sensor, T, S = opt(argv, "--sensor", "HDL-64", str), opt(argv, "--frames", 3), opt(argv, "--sequences", 4)
     out = {}
+    travel = "--travel" in argv           # sweeps of the travelling drive (a-loam_amd/synthetic.py `travel`), skipping the slow first `--skip` frames
+    skip = opt(argv, "--skip", 20)
     for s in range(S):
-        scans, _, _, model = syn.make_sequence(sensor, T, seed=100 + s)
+        if travel:
+            scans, _, _, model = syn.make_sequence(sensor, skip + T, seed=100 + s, travel=True, step=1.6)
+            scans = scans[skip:]
+        else:
+            scans, _, _, model = syn.make_sequence(sensor, T, seed=100 + s)
         for k, x in enumerate(scans):
             out[f"s{s}_f{k}"] = x.numpy().astype(np.float32)
     out["meta"] = np.array(json.dumps({"sensor": sensor, "frames": T, "sequences": S, "n_scans": model.n_scans, "min_range": model.min_range,
