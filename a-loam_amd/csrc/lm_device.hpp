@@ -115,7 +115,8 @@ struct LmResult { int iterations, successful, termination, n_a, n_b; double init
 // The whole ceres::Solve stand-in for one sequence, executed by one 256-thread workgroup.  Every thread runs the (uniform)
 // scalar LM logic redundantly; only the evaluations are distributed.  `eval(with_jac, q, t, acc, &n_a, &n_b)` adds this
 // thread's share of the robustified sums at (q, t): acc[0..20] upper triangle of J^T J, acc[21..26] J^T r, acc[27] cost, and
-// counts the residual blocks of the two factor classes it visited.  q (xyzw) and t are updated in place.
+// counts the residual blocks of the two factor classes it visited.  q (xyzw) and t are updated in place; after termination 5 (FAILURE) the
+// caller must put the values it passed in back, as ceres::Solve does with a solution that is not usable.
 __device__ __forceinline__ bool all_finite(const double* v, int n) { bool f = true; for (int k = 0; k < n; ++k) f = f && isfinite(v[k]); return f; }
 
 template <int NW = 4, class Eval>
@@ -189,7 +190,7 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
         model_change = -sg - 0.5 * shs;                   // -(J s)^T (r + J s / 2)
       }
       if (!ok || !(model_change > 0.0)) {
-        if (++n_invalid >= 5) { termination = 5; break; }
+        if (++n_invalid >= 5) { termination = 5; cost = initial_cost; break; }   // FAILURE: the caller restores the entry parameters (see the accepted step)
         radius = radius / decrease_factor;
         decrease_factor *= 2.0;
         continue;
@@ -215,16 +216,18 @@ __device__ __forceinline__ LmResult lm_solve_block(Eval&& eval, double q[4], dou
       if (fabs(cost - cost_c) <= kFunctionTol * cost) { termination = 2; break; }
       const double rel = (cost - cost_c) / model_change;
       if (rel > kMinRelDecrease) {
+        // HandleSuccessfulStep(): a Jacobian that cannot be evaluated at the accepted point ends the solve as FAILURE, and a failed solve
+        // leaves the user's parameters as they were at entry (Ceres writes x back only from a usable solution): the caller re-reads them
+        // (termination 5), the step is not counted, the cost reported is the initial one.  (The sums are tested, not the entries: a finite
+        // entry beyond ~1e154 overflows in J^T J and reads as non-finite here, where Ceres and the CPU restatements used by the tests
+        // would go on — no real sweep comes within 150 orders of magnitude of that.)
+        if (!all_finite(cacc, 28)) { termination = 5; cost = initial_cost; break; }
         for (int k = 0; k < 4; ++k) q[k] = qc[k];
         for (int k = 0; k < 3; ++k) t[k] = tc[k];
         x_norm = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] + t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
         for (int k = 0; k < 28; ++k) acc[k] = cacc[k];
         cost = acc[27];
         ++successful;
-        // HandleSuccessfulStep(): x is the candidate now; a Jacobian that cannot be evaluated there ends the solve as FAILURE.  (The sums
-        // are tested, not the entries: a finite entry beyond ~1e154 overflows in J^T J and reads as non-finite here, where Ceres and
-        // the CPU restatements used by the tests would go on — no real sweep comes within 150 orders of magnitude of that.)
-        if (!all_finite(acc, 28)) { termination = 5; break; }
         unpack(acc);
         gmax = gradient_max();
         apply_scale();

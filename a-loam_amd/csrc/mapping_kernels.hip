@@ -1415,6 +1415,10 @@ __global__ __launch_bounds__(kMapSolveThreads) void k_map_solve(MapArgs a, int i
     if (with_jac) map_evaluate<true>(a, b, s_pref, qq, tt, acc, ne, np); else map_evaluate<false>(a, b, s_pref, qq, tt, acc, ne, np);
   }, q, t, a.lm_max_iterations, s_red);
   if (tid == 0) {
+    if (lm.termination == 5) {                                               // FAILURE: `parameters` stay what they were (ceres::Solve restores them)
+      for (int k = 0; k < 4; ++k) q[k] = ms.par[k];
+      for (int k = 0; k < 3; ++k) t[k] = ms.par[4 + k];
+    }
     for (int k = 0; k < 4; ++k) ms.par[k] = q[k];
     for (int k = 0; k < 3; ++k) ms.par[4 + k] = t[k];
     ms.factor_num[iter][0] = lm.n_a;

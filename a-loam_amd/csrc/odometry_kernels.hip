@@ -134,13 +134,8 @@ __device__ __forceinline__ void deskew_jacobian_row(const double a[3], const dou
 // way scan registration emits it).  On ring-sorted clouds the reference's walk-until-break loops visit exactly the points
 // whose key lies within +-2 of the closest point's; clouds that are not sorted (possible through aloam_set_last) take the
 // literal walks, and clouds with huge coordinates or keys (flags[0]) the literal brute-force search as well.
-#ifndef ALOAM_CELL3_SURF
-#define ALOAM_CELL3_SURF 0.5f      // A/B builds (values with few mantissa bits only: cell borders must be exact f32 numbers)
-#endif
-#ifndef ALOAM_CELL3_CORNER
-#define ALOAM_CELL3_CORNER 0.75f   // measured (k_associate[corner], two launches, batch 1024): 1.25 m 1.13 ms, 1.0 m 1.106, 0.75 m 1.048, 0.625 m 1.074, 0.5 m 1.159;
-#endif                             // the planar class: 0.375 m 2.90 ms, 0.5 m 2.84, 0.625 m 3.01
-constexpr float kCell3Surf = ALOAM_CELL3_SURF, kCell3Corner = ALOAM_CELL3_CORNER;
+constexpr float kCell3Surf = 0.5f;   // values with few mantissa bits only: cell borders must be exact f32 numbers
+constexpr float kCell3Corner = 0.75f;   // measured (k_associate[corner], two launches, batch 1024): 1.25 m 1.13 ms, 1.0 m 1.106, 0.75 m 1.048, 0.625 m 1.074, 0.5 m 1.159; the planar class: 0.375 m 2.90 ms, 0.5 m 2.84, 0.625 m 3.01
 // A 1-NN query whose neighbour is not inside the first block of fine cells continues on cells four times as large, so the work
 // of a far query is bounded by a few dozen bucket look-ups instead of growing with the cube of the radius.  The ring grid has
 // one level of 2.625 m cells: its 3x3 block already settles 95 % of the searches that reach it (most never do: the fine 1-NN
@@ -160,10 +155,6 @@ __device__ __forceinline__ unsigned hash3(int a, int b, int c) {
 // scattered 16-byte copies are written from the same registers.  16-bit offsets hold clouds of up to 65535 points (every synthetic
 // and KITTI-sized HDL-64 cloud); larger clouds (128-ring stress input) and tables above 16384 buckets keep the per-grid workgroups
 // of k_build_grids.  Traffic per point: 2 x 16 B read + 3 x 16 B written, against 6 x 16 + 3 x 16.
-#ifndef ALOAM_COARSE_VIA
-#define ALOAM_COARSE_VIA 0      // A/B builds: 1 = the coarse level of the fused build holds 16-bit positions into the fine copy instead of its
-                                // own 16-byte copy.  Measured on one box, same run: k_build_grids 1.42 -> 1.31 ms, k_associate[plane] 2.84 -> 3.25 ms
-#endif
 constexpr int kFusedMaxN = 65535, kFusedMaxH = 16384;
 constexpr int kWalkKeys = kMaxRings + 8;
 
@@ -205,14 +196,8 @@ __device__ __forceinline__ void walk_tables(const float4* __restrict__ pts, int 
 }
 __host__ __device__ __forceinline__ bool fused_takes(int n, int H) { return n <= kFusedMaxN && H <= kFusedMaxH; }
 
-#ifdef ALOAM_BG_TIMING   // variant builds: one surf workgroup prints the duration of its phases (device timer, 10 ns units)
-#define BG_T(tag) do { __syncthreads(); if (blockIdx.x == 1 && blockIdx.y == 5 && threadIdx.x == 0) { const long long t_ = wall_clock64(); printf("k_build_grids_fused phase %d : %d x10ns (n = %d)\n", tag, (int)(t_ - bg_t_prev), n); bg_t_prev = wall_clock64(); } } while (0)
-#else
-#define BG_T(tag) do { } while (0)
-#endif
 __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
   constexpr int U = 4;
-  long long bg_t_prev = wall_clock64(); (void)bg_t_prev;
   const int b = blockIdx.y, which = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const SeqMeta m = a.meta[b];
   const int n = which == 0 ? m.n_corner_last : m.n_surf_last;
@@ -226,19 +211,14 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
   int* s_flag = s_part + 48;                            // bad, unsorted
   int* s_walk = s_flag + 8;                             // [2][kWalkKeys] first / last index of every ring key (clouds with a descending key only)
   int* const starts[3] = {g.start3, g.start3c, g.start2};
-  // ALOAM_COARSE_VIA builds only: the coarse level gets no 16-byte copy of its own, an entry is the 16-bit POSITION of the point in
-  // the fine copy (same buffer, read as unsigned short; flags[2] tells k_associate).  Both that and the ring grid as positions were
-  // measured and rejected: what the grid build saves in stores, the extra hop costs the association twice over.
-  unsigned short* const pos_list = reinterpret_cast<unsigned short*>(g.sorted3c);
   if (n == 0) {
     for (int t = 0; t < 3; ++t) for (int h = tid; h <= H; h += 1024) starts[t][h] = 0;
-    if (tid < 3) g.flags[tid] = tid == 2 ? ALOAM_COARSE_VIA : 0;
+    if (tid < 3) g.flags[tid] = 0;
     return;
   }
   for (int w = tid; w < 3 * (H / 2); w += 1024) tab[w] = 0u;
   if (tid < 2) s_flag[tid] = 0;
   __syncthreads();
-  BG_T(0);
   const float inv0 = 1.0f / cell3_of(which), inv1 = 1.0f / (cell3_of(which) * kCell3CoarseFactor), inv2 = 1.0f / kCell2;
   const unsigned hm = (unsigned)(H - 1);
   auto buckets = [&](const float4& p, int key, unsigned* h) {
@@ -275,9 +255,8 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
     if (unsorted) atomicOr(&s_flag[1], 1);
   }
   __syncthreads();
-  BG_T(1);
   if (s_flag[1] && !s_flag[0]) walk_tables(pts, n, a.R, g.walk, s_walk, s_flag, tid);    // some key is lower than its predecessor's: nearly sorted or not at all?
-  if (tid < 3) g.flags[tid] = tid == 2 ? ALOAM_COARSE_VIA : s_flag[tid];
+  if (tid < 3) g.flags[tid] = tid == 2 ? 0 : s_flag[tid];
   // ---- exclusive scans of the three tables: every thread owns H / 1024 consecutive buckets (= H / 2048 words) of each
   {
     const int wpt = H / 2048;                                              // words per thread and table (2 at H = 4096, 8 at 16384)
@@ -307,7 +286,6 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
     }
   }
   __syncthreads();
-  BG_T(2);
   // ---- fill: the three copies of every point from one read
   for (int base = 0; base < n; base += U * 1024) {
     float4 p[U];
@@ -327,28 +305,20 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
       }
       const float4 e = make_float4(p[u].x, p[u].y, p[u].z, __uint_as_float((unsigned)i | ((unsigned)(key + 1) << 20)));
       g.sorted3[pos[0]] = e;
-      if (ALOAM_COARSE_VIA) pos_list[pos[1]] = (unsigned short)pos[0]; else g.sorted3c[pos[1]] = e;
+      g.sorted3c[pos[1]] = e;
       g.sorted2[pos[2]] = e;
     }
   }
-  BG_T(3);
 }
 
-#ifndef ALOAM_BG_WAVES
-#define ALOAM_BG_WAVES 4      // waves per SIMD the register budget is sized for (A/B builds)
-#endif
-#ifndef ALOAM_BG_SPLIT
-#define ALOAM_BG_SPLIT 1      // measured at batch 512: 2 workgroups x 3 passes 1.16 ms, 6 workgroups x 1 pass 0.85 ms
-#endif
-#ifndef ALOAM_BG_UNROLL
-#define ALOAM_BG_UNROLL 4
-#endif
-__global__ __launch_bounds__(1024, ALOAM_BG_WAVES) void k_build_grids(OdomArgs a) {
-  constexpr int U = ALOAM_BG_UNROLL;                                     // loads in flight per thread
+constexpr int kBgWaves = 4;   // waves per SIMD the register budget is sized for
+constexpr int kBgUnroll = 4;
+__global__ __launch_bounds__(1024, kBgWaves) void k_build_grids(OdomArgs a) {
+  constexpr int U = kBgUnroll;                                     // loads in flight per thread
   // one workgroup per (sequence, cloud, grid): the three grids of a cloud are independent, and six workgroups per sequence
   // overlap each other's load / LDS-atomic / scattered-store phases better than two that run three passes back to back
-  const int b = blockIdx.y, which = ALOAM_BG_SPLIT ? blockIdx.x / 3 : blockIdx.x, tid = threadIdx.x;      // which: 0 corner_last, 1 surf_last
-  const int pass_lo = ALOAM_BG_SPLIT ? blockIdx.x % 3 : 0, pass_hi = ALOAM_BG_SPLIT ? pass_lo + 1 : 3;
+  const int b = blockIdx.y, which = blockIdx.x / 3, tid = threadIdx.x;      // which: 0 corner_last, 1 surf_last
+  const int pass_lo = blockIdx.x % 3, pass_hi = pass_lo + 1;
   const SeqMeta m = a.meta[b];
   const int n = which == 0 ? m.n_corner_last : m.n_surf_last;
   const float4* pts = which == 0 ? a.corner_last + (long long)b * a.R * 120 : a.surf_last + (long long)b * a.cap;
@@ -456,11 +426,7 @@ __device__ __forceinline__ float walk_dist(const float4& p, const float4& sel) {
   return (p.x - sel.x) * (p.x - sel.x) + (p.y - sel.y) * (p.y - sel.y) + (p.z - sel.z) * (p.z - sel.z);
 }
 
-#ifndef ALOAM_ASSOC_MIN64
-#define ALOAM_ASSOC_MIN64 0     // A/B builds: 1 = the 64-bit xor-butterfly reduction of round 1
-#endif
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
-  if (ALOAM_ASSOC_MIN64) return wave_extreme_u64<false>(v, (int)(threadIdx.x & 63));
   return wave_min_packed(v);                                               // DPP ladder on the distance word, tie-break only on exact ties
 }
 
@@ -490,11 +456,8 @@ __device__ __forceinline__ void shell3d(int r, int c, int* dx, int* dy, int* dz)
 // 2 for the corner class (measured: a third row only costs there).
 template <int kSweep> struct Kept { float4 p[kSweep]; bool a[kSweep]; bool ok; };
 
-// `via`: the list holds 16-bit positions into `sorted` instead of the entries themselves (coarse level of k_build_grids_fused): one
-// more, L2-resident, hop per candidate in exchange for 14 bytes per point the grid build does not write.
 template <int kSweep, class F>
-__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f, Kept<kSweep>* keep = nullptr,
-                                           const unsigned short* __restrict__ via = nullptr) {
+__device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, int s0, int cnt, int lane, int* row, F&& f, Kept<kSweep>* keep = nullptr) {
   const int incl = wave_scan_i32<false>(cnt);
   const int total = __builtin_amdgcn_readlane(incl, 63);
   const int excl = incl - cnt;
@@ -522,7 +485,7 @@ __device__ __forceinline__ void wave_sweep(const float4* __restrict__ sorted, in
         const int i = base + u * 64 + lane;
         const int os = __shfl(s0, own[u] - 1, 64), oe = __shfl(excl, own[u] - 1, 64);
         const int at = i < total ? os + (i - oe) : 0;
-        p[u] = sorted[via ? (int)via[at] : at];
+        p[u] = sorted[at];
       }
     }
 #pragma unroll
@@ -603,8 +566,7 @@ __device__ __forceinline__ unsigned long long wave_nn(const GridView& g, bool ba
             cnt = g.start3c[h + 1] - s0;
           }
         }
-        if (ALOAM_COARSE_VIA && g.flags[2]) wave_sweep<kSweep>(g.sorted3, s0, cnt, lane, row, visit, nullptr, reinterpret_cast<const unsigned short*>(g.sorted3c));
-        else wave_sweep<kSweep>(g.sorted3c, s0, cnt, lane, row, visit);
+        wave_sweep<kSweep>(g.sorted3c, s0, cnt, lane, row, visit);
       }
       best = wave_min_u64(mine.v);
       const float bc = ((float)r - 0.01f) * cellc, b2 = bc * bc;
@@ -661,16 +623,11 @@ __global__ __launch_bounds__(256) void k_transform_queries(OdomArgs a) {
 // workgroup 1.90 ms, 4: 1.63, 2: 1.53, 1: 1.47 — a freed SIMD slot is refilled soonest when nothing else has to retire with it.
 // Persistent waves (exactly the resident number, each walking through 1 / W of the queries of its XCD's sequences) were measured
 // too: 1.84 ms — the loop carries 75 VGPRs instead of 64 (6 waves per SIMD instead of 8) and the kernel lives off occupancy.
-#ifndef ALOAM_ASSOC_SWEEP_WIDE
-#define ALOAM_ASSOC_SWEEP_WIDE 6     // rows of 64 candidates in flight per wave, planar class, sensors with more than 64 rings.  Measured on the
-                                     // 128 x 2048 stress sweeps (two launches, batch 1024): 3 rows 7.65 ms, 4: 7.70, 5: 7.14, 6: 6.64, 8: 8.69, 10: 11.8
-#endif
-#ifndef ALOAM_ASSOC_SWEEP_PLANE
-#define ALOAM_ASSOC_SWEEP_PLANE 3    // the same for sensors with up to 64 rings (HDL-64, batch 1024: 3 rows 2.83 ms, 4 rows 3.03 ms)
-#endif
-template <bool PLANE, bool WIDE> struct SweepRows { static constexpr int value = WIDE ? (PLANE ? ALOAM_ASSOC_SWEEP_WIDE : 3) : (PLANE ? ALOAM_ASSOC_SWEEP_PLANE : 2); };
+constexpr int kAssocSweepWide = 6;   // rows of 64 candidates in flight per wave, planar class, sensors with more than 64 rings.  Measured on the 128 x 2048 stress sweeps (two launches, batch 1024): 3 rows 7.65 ms, 4: 7.70, 5: 7.14, 6: 6.64, 8: 8.69, 10: 11.8
+constexpr int kAssocSweepPlane = 3;   // the same for sensors with up to 64 rings (HDL-64, batch 1024: 3 rows 2.83 ms, 4 rows 3.03 ms)
+template <bool PLANE, bool WIDE> struct SweepRows { static constexpr int value = WIDE ? (PLANE ? kAssocSweepWide : 3) : (PLANE ? kAssocSweepPlane : 2); };
 
-template <bool PLANE, bool DISTORT, bool WIDE>
+template <bool PLANE, bool WIDE>
 __device__ __forceinline__ void associate_one(const OdomArgs& a, int b, int qi, const SeqMeta& m, const GridView& g, int lane, int* row) {
   constexpr int kSweep = SweepRows<PLANE, WIDE>::value;
   const int qcap = PLANE ? a.R * 24 : a.R * 12;
@@ -822,22 +779,6 @@ __device__ __forceinline__ void associate_one(const OdomArgs& a, int b, int qi, 
   }
 }
 
-template <bool PLANE, bool DISTORT, bool WIDE = false>
-__global__ __launch_bounds__(64) void k_associate(OdomArgs a) {
-  // XCD-aware work mapping: workgroups are dispatched round-robin over the 8 XCDs by linear id and every XCD has its own 4 MiB L2.
-  // The grids of one sequence (~1.5 MB) are shared by all waves working on that sequence, so the linear id is re-mapped such that
-  // XCD x works through sequences x, x+8, x+16, ...: each L2 holds a few sequences' grids instead of thrashing on all of them.
-  // (Pure placement: any mapping gives the same result.)
-  constexpr int kSweep = SweepRows<PLANE, WIDE>::value;
-  __shared__ int row[kSweep * 64];
-  const int lane = threadIdx.x, L = blockIdx.x, xcd = L & 7, slot = L >> 3;
-  const int qcap = PLANE ? a.R * 24 : a.R * 12;
-  const int b = (slot / qcap) * 8 + xcd, qi = slot % qcap;
-  if (b >= a.B) return;
-  const SeqMeta m = a.meta[b];
-  if (qi >= (PLANE ? m.n_flat : m.n_sharp)) return;
-  associate_one<PLANE, DISTORT, WIDE>(a, b, qi, m, grid_view(a, b, PLANE ? 1 : 0), lane, row);
-}
 
 // -------------------------------------------------------------------------------------------------------
 // TWO queries per wave (round 4).  The wave-per-query kernel above spends two thirds of its ~600 VALU instructions per query on
@@ -911,9 +852,6 @@ __device__ __forceinline__ float dist_to(const float4& p, float2v sxy, float sz)
   return (qxy.x + qxy.y) + ddz * ddz;                                         // FLANN's L2_Simple sum = the walk's f32 expression (:322-327)
 }
 
-#ifndef ALOAM_FINE_EXACT_RADIUS
-#define ALOAM_FINE_EXACT_RADIUS 1   // A/B builds: 0 = 0.99 cells for every query
-#endif
 template <bool HALVES, int kRows, class F>
 __device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsigned last_index, int s0, int cnt, int lane, int last4, int* lds, F&& f, bool* single_round = nullptr, int* rows_first = nullptr, int stat_cls = 0, int stat_slot = -1) {
   constexpr int W = HALVES ? 32 : 64, LOGW = HALVES ? 5 : 6, kSlots = HALVES ? 2 * kRows : kRows;
@@ -988,23 +926,11 @@ __device__ __forceinline__ void sweep2(const float4* __restrict__ sorted, unsign
   }
 }
 
-#ifndef ALOAM_ASSOC_DEBUG_LDS
-#define ALOAM_ASSOC_DEBUG_LDS 0     // occupancy experiments: dynamic LDS bytes per (single-wave) workgroup of k_associate_pair, used by nothing
-#endif                              // (round 5: 9 500 / 19 500 bytes = 4 / 2 waves per SIMD instead of 7: planar +38 % / +139 %, corner +48 % / +159 %)
-#ifndef ALOAM_PAIR_TAILS
-#define ALOAM_PAIR_TAILS 1           // A/B builds: 0 = the tails always one query at a time
-#endif
-#ifndef ALOAM_PAIR_ROWS_PLANE
-#define ALOAM_PAIR_ROWS_PLANE 6      // rows of 32 candidates per half in flight / kept (A/B builds)
-#endif
-#ifndef ALOAM_PAIR_ROWS_CORNER
-#define ALOAM_PAIR_ROWS_CORNER 4
-#endif
-#ifndef ALOAM_PAIR_ROWS_WIDE
-#define ALOAM_PAIR_ROWS_WIDE 8
-#endif
-template <bool PLANE, bool WIDE> struct PairRows { static constexpr int value = WIDE ? (PLANE ? ALOAM_PAIR_ROWS_WIDE : ALOAM_PAIR_ROWS_PLANE) : (PLANE ? ALOAM_PAIR_ROWS_PLANE : ALOAM_PAIR_ROWS_CORNER);
-                                                   static_assert(value >= 1 && value <= 8, "ALOAM_PAIR_ROWS_*: 1 .. 8 rows (sweep2's mark slots)"); };
+constexpr int kPairRowsPlane = 6;   // rows of 32 candidates per half in flight / kept
+constexpr int kPairRowsCorner = 4;
+constexpr int kPairRowsWide = 8;
+template <bool PLANE, bool WIDE> struct PairRows { static constexpr int value = WIDE ? (PLANE ? kPairRowsWide : kPairRowsPlane) : (PLANE ? kPairRowsPlane : kPairRowsCorner);
+                                                   static_assert(value >= 1 && value <= 8, "kPairRows*: 1 .. 8 rows (sweep2's mark slots)"); };
 
 __device__ __forceinline__ unsigned long long nn_key(float d, unsigned wb) { return ((unsigned long long)__float_as_uint(d) << 32) | ((wb & kIdxMask) << 12) | (wb >> 20); }
 __device__ __forceinline__ void take_min(unsigned long long& t, unsigned long long v) { t = v < t ? v : t; }
@@ -1124,13 +1050,10 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
 // are skipped — the own cell first because its ~50 candidates usually bound the search to one or two of the eight cells (and their ~400 candidates).
 // Measured (batch 1024, two launches; per query pair the planar class sweeps 47 + 95 candidates in 0.98 + 0.85 stages instead of 214 in 1.04):
 // planar class 2.23 -> 2.17 ms, corner class (a third of the candidates, so the extra stage costs more than it prunes) 0.754 -> 0.817 ms.
-#ifndef ALOAM_RING_OWN_CELL_FIRST
-#define ALOAM_RING_OWN_CELL_FIRST PLANE   // A/B builds: 0 = the 3x3 block in one stage, 1 = own cell first for both classes
-#endif
 template <bool PLANE, int kRows, bool HALVES, bool NEARLY>
 __device__ __forceinline__ void ring_grid(const GridView& g, unsigned last_index, float sx, float sy, float sz, int closest, int cid, bool want2, bool want3,
                                           unsigned long long& best2, unsigned long long& best3, int lane, int last4, int* lds, int lo, int hi) {
-  constexpr bool kOwnFirst = ALOAM_RING_OWN_CELL_FIRST;
+  constexpr bool kOwnFirst = PLANE;                                     // the own cell as a stage of its own: pays for the planar class only (corner: 0.754 -> 0.817 ms)
   constexpr int W = HALVES ? 32 : 64;
   const int l = lane & (W - 1);
   const unsigned hm = (unsigned)(g.H - 1);
@@ -1245,7 +1168,7 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
     const float inv = 1.0f / cell;
     const float lx = floorf(sel.x * inv) * cell, ly = floorf(sel.y * inv) * cell, lz = floorf(sel.z * inv) * cell;
     const float gap = fminf(fminf(fminf(sel.x - lx, (lx + cell) - sel.x), fminf(sel.y - ly, (ly + cell) - sel.y)), fminf(sel.z - lz, (lz + cell) - sel.z));
-    const float b = (1.0f - 0.01f) * (ALOAM_FINE_EXACT_RADIUS ? cell + (gap > 1e-3f ? gap - 1e-3f : 0.f) : cell);
+    const float b = (1.0f - 0.01f) * (cell + (gap > 1e-3f ? gap - 1e-3f : 0.f));
     fine_b2 = b * b;
   }
   {
@@ -1307,9 +1230,6 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
       for (int q = 0; q < 2; ++q) {
         const bool q2 = (w2 >> (32 * q)) & 1ull, q3 = (w3 >> (32 * q)) & 1ull;
         if (!(q2 || q3)) continue;
-#ifdef ALOAM_DEBUG_SKIP_RING
-        continue;                                                              // timing experiments only: wrong results
-#endif
         unsigned long long r2 = read_u64(best2, 32 * q), r3 = read_u64(best3, 32 * q);
         ring_grid<PLANE, kRows1, false, NEARLY>(g, last_index, read_f32(sel.x, 32 * q), read_f32(sel.y, 32 * q), read_f32(sel.z, 32 * q), __builtin_amdgcn_readlane(closest, 32 * q),
                                                 __builtin_amdgcn_readlane(cid, 32 * q), q2, q3, r2, r3, lane, 0, lds, __builtin_amdgcn_readlane(wlo, 32 * q), __builtin_amdgcn_readlane(whi, 32 * q));
@@ -1344,11 +1264,8 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
   }
 }
 
-#ifndef ALOAM_PAIR_OCC
-#define ALOAM_PAIR_OCC                   // A/B builds: e.g. -DALOAM_PAIR_OCC='__attribute__((amdgpu_waves_per_eu(8)))'
-#endif
 template <bool PLANE, bool WIDE>
-__global__ __launch_bounds__(64) ALOAM_PAIR_OCC void k_associate_pair(OdomArgs a) {
+__global__ __launch_bounds__(64) void k_associate_pair(OdomArgs a) {
   constexpr int kRows = PairRows<PLANE, WIDE>::value;
   __shared__ int lds[sweep2_lds_ints<kRows>()];
   // XCD-aware work mapping as in k_associate: XCD x works through sequences x, x + 8, ...
@@ -1363,7 +1280,7 @@ __global__ __launch_bounds__(64) ALOAM_PAIR_OCC void k_associate_pair(OdomArgs a
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
   if (g.flags[0] != 0 || g.flags[1] != 0 || nt <= 0) return;                 // k_associate_nearly / k_associate_flagged own this sequence
   // (128-ring sensors: the paired tails would take the planar class from 79 to 85 registers, six waves per SIMD to five, for their ~1 %)
-  associate_pair<PLANE, kRows, ALOAM_PAIR_TAILS && !WIDE, false>(a, b, qi0, nq, nt, g, lane, lds);
+  associate_pair<PLANE, kRows, !WIDE, false>(a, b, qi0, nq, nt, g, lane, lds);
 }
 
 // Sequences whose last cloud is NEARLY ring-sorted (flags[1] == 1, walk_tables above: a sweep whose first ray had no return - a handful of
@@ -1384,14 +1301,14 @@ __global__ __launch_bounds__(64) void k_associate_nearly(OdomArgs a) {
   for (int k = 0; k < kPairsPerWave; ++k) {
     const int qi0 = (blockIdx.x * kPairsPerWave + k) * 2;
     if (qi0 >= nq) return;
-    associate_pair<PLANE, kRows, ALOAM_PAIR_TAILS && !WIDE, true>(a, b, qi0, nq, nt, g, lane, lds);
+    associate_pair<PLANE, kRows, !WIDE, true>(a, b, qi0, nq, nt, g, lane, lds);
   }
 }
 
 // Sequences the pair kernel leaves alone: clouds that are not ring-sorted or hold keys / coordinates outside the range the grids are
 // exact for (possible through aloam_set_last), and empty clouds.  One workgroup of four waves per sequence walks through its queries with
 // the literal one-query code; for every other sequence the workgroup returns at once.
-template <bool PLANE, bool DISTORT, bool WIDE>
+template <bool PLANE, bool WIDE>
 __global__ __launch_bounds__(256) void k_associate_flagged(OdomArgs a) {
   constexpr int kSweep = SweepRows<PLANE, WIDE>::value;
   __shared__ int rows[4][kSweep * 64];
@@ -1401,14 +1318,12 @@ __global__ __launch_bounds__(256) void k_associate_flagged(OdomArgs a) {
   const int nt = PLANE ? m.n_surf_last : m.n_corner_last;
   if (!(g.flags[0] != 0 || g.flags[1] == 2 || nt <= 0)) return;
   const int nq = PLANE ? m.n_flat : m.n_sharp;
-  for (int qi = wave; qi < nq; qi += 4) associate_one<PLANE, DISTORT, WIDE>(a, b, qi, m, g, lane, rows[wave]);
+  for (int qi = wave; qi < nq; qi += 4) associate_one<PLANE, WIDE>(a, b, qi, m, g, lane, rows[wave]);
 }
 
 // -------------------------------------------------------------------------------------------------------
-#ifndef ALOAM_SOLVE_WAVES
-#define ALOAM_SOLVE_WAVES 2      // waves per sequence in k_solve; measured at batch 512: 1: 0.62 ms, 2: 0.44, 4: 0.53, 8: 0.87 (two launches)
-#endif
-constexpr int kSolveWaves = ALOAM_SOLVE_WAVES, kSolveThreads = 64 * kSolveWaves;
+constexpr int kSolveWaves = 2;   // waves per sequence in k_solve; measured at batch 512: 1: 0.62 ms, 2: 0.44, 4: 0.53, 8: 0.87 (two launches)
+constexpr int kSolveThreads = 64 * kSolveWaves;
 template <bool WITH_JAC, bool DISTORT>
 __device__ void evaluate(const OdomArgs& a, int b, const double q[4], const double t[3], double* acc, int* n_edge, int* n_plane) {
   const int tid = threadIdx.x;
@@ -1507,6 +1422,10 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(OdomArgs a) {
   const double initial_cost = lm.initial_cost, cost = lm.final_cost;
 
   if (tid == 0) {
+    if (termination == 5) {                               // FAILURE: para_q / para_t stay what they were (ceres::Solve restores them)
+      for (int k = 0; k < 4; ++k) q[k] = st.para_q[k];
+      for (int k = 0; k < 3; ++k) t[k] = st.para_t[k];
+    }
     for (int k = 0; k < 4; ++k) st.para_q[k] = q[k];
     for (int k = 0; k < 3; ++k) st.para_t[k] = t[k];
     const int o = a.outer < 2 ? a.outer : 1;
@@ -1553,58 +1472,29 @@ void launch_build_grids(const OdomArgs& a, hipStream_t s) {
   // that can be fused)
   const int hc = a.grid_H_corner <= kFusedMaxH ? a.grid_H_corner : 0, hs = a.grid_H_surf <= kFusedMaxH ? a.grid_H_surf : 0;
   if (hc || hs) hipLaunchKernelGGL(k_build_grids_fused, dim3(2, a.B), dim3(1024), build_grids_fused_lds_bytes(hc > hs ? hc : hs), s, a);
-  hipLaunchKernelGGL(k_build_grids, dim3(ALOAM_BG_SPLIT ? 6 : 2, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
+  hipLaunchKernelGGL(k_build_grids, dim3(6, a.B), dim3(1024), build_grids_lds_bytes(a.grid_H_surf, a.R), s, a);
 }
 void launch_transform_queries(const OdomArgs& a, hipStream_t s) {
   const dim3 grid((a.R * 36 + 255) / 256, a.B);
   if (a.distortion) hipLaunchKernelGGL(k_transform_queries<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_transform_queries<false>, grid, dim3(256), 0, s, a);
 }
-#ifndef ALOAM_ASSOC_PAIR
-#define ALOAM_ASSOC_PAIR 2      // A/B builds: 0 = the one-query-per-wave kernel of rounds 1-3, 1 = two queries per wave for the corner class
-#endif                          // (measured, batch 1024, two launches: corner 1.048 -> 0.875 ms, planar 2.85 -> 3.03 ms), 2 = for both classes
 void launch_associate(const OdomArgs& a, bool plane, hipStream_t s) {
-  const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate)
+  const int by = (a.B + 7) / 8 * 8;      // padded so that every (XCD, sequence slot) pair exists (see k_associate_pair)
   const int qcap = plane ? a.R * 24 : a.R * 12;   // the kernel decodes (sequence, query) from blockIdx.x with exactly this slot count
   // sensors with more than 64 rings: the ring grid's +-2-ring window and the fine blocks hold about twice the candidates, so the
   // waves keep more rows of candidates in flight per sweep round (rows by class AND ring count)
   const bool wide = a.R > 64;
-  if (ALOAM_ASSOC_PAIR == 2 || (ALOAM_ASSOC_PAIR == 1 && !plane)) {
-    const dim3 grid((unsigned)(qcap / 2 * by)), block(64), gridf((unsigned)a.B), blockf(256);
-    if (wide) {
-      if (plane) hipLaunchKernelGGL((k_associate_pair<true, true>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
-      else hipLaunchKernelGGL((k_associate_pair<false, true>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
-    } else {
-      if (plane) hipLaunchKernelGGL((k_associate_pair<true, false>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
-      else hipLaunchKernelGGL((k_associate_pair<false, false>), grid, block, ALOAM_ASSOC_DEBUG_LDS, s, a);
-    }
-    const dim3 gridn((unsigned)((qcap / 2 + kPairsPerWave - 1) / kPairsPerWave), (unsigned)a.B);
-    if (wide) {
-      if (plane) hipLaunchKernelGGL((k_associate_nearly<true, true>), gridn, block, 0, s, a);
-      else hipLaunchKernelGGL((k_associate_nearly<false, true>), gridn, block, 0, s, a);
-    } else {
-      if (plane) hipLaunchKernelGGL((k_associate_nearly<true, false>), gridn, block, 0, s, a);
-      else hipLaunchKernelGGL((k_associate_nearly<false, false>), gridn, block, 0, s, a);
-    }
-    if (wide) {
-      if (plane) hipLaunchKernelGGL((k_associate_flagged<true, false, true>), gridf, blockf, 0, s, a);
-      else hipLaunchKernelGGL((k_associate_flagged<false, false, true>), gridf, blockf, 0, s, a);
-    } else {
-      if (plane) hipLaunchKernelGGL((k_associate_flagged<true, false, false>), gridf, blockf, 0, s, a);
-      else hipLaunchKernelGGL((k_associate_flagged<false, false, false>), gridf, blockf, 0, s, a);
-    }
-    return;
-  }
-  const dim3 grid((unsigned)(qcap * by)), block(64);
-  if (a.distortion) {
-    if (plane) hipLaunchKernelGGL((k_associate<true, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_associate<false, true>), grid, block, 0, s, a);
-  } else if (wide) {
-    if (plane) hipLaunchKernelGGL((k_associate<true, false, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_associate<false, false, true>), grid, block, 0, s, a);
+  // every sequence belongs to exactly one of the three kernels (flags of its last cloud, k_build_grids_fused): ring-sorted -> pair kernel,
+  // nearly ring-sorted -> pair code with the index-range walk window, anything else -> literal one-query walks; the other two return at once
+  const dim3 grid((unsigned)(qcap / 2 * by)), block(64), gridf((unsigned)a.B), blockf(256);
+  const dim3 gridn((unsigned)((qcap / 2 + kPairsPerWave - 1) / kPairsPerWave), (unsigned)a.B);
+  if (wide) {
+    if (plane) { hipLaunchKernelGGL((k_associate_pair<true, true>), grid, block, 0, s, a); hipLaunchKernelGGL((k_associate_nearly<true, true>), gridn, block, 0, s, a); hipLaunchKernelGGL((k_associate_flagged<true, true>), gridf, blockf, 0, s, a); }
+    else { hipLaunchKernelGGL((k_associate_pair<false, true>), grid, block, 0, s, a); hipLaunchKernelGGL((k_associate_nearly<false, true>), gridn, block, 0, s, a); hipLaunchKernelGGL((k_associate_flagged<false, true>), gridf, blockf, 0, s, a); }
   } else {
-    if (plane) hipLaunchKernelGGL((k_associate<true, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_associate<false, false>), grid, block, 0, s, a);
+    if (plane) { hipLaunchKernelGGL((k_associate_pair<true, false>), grid, block, 0, s, a); hipLaunchKernelGGL((k_associate_nearly<true, false>), gridn, block, 0, s, a); hipLaunchKernelGGL((k_associate_flagged<true, false>), gridf, blockf, 0, s, a); }
+    else { hipLaunchKernelGGL((k_associate_pair<false, false>), grid, block, 0, s, a); hipLaunchKernelGGL((k_associate_nearly<false, false>), gridn, block, 0, s, a); hipLaunchKernelGGL((k_associate_flagged<false, false>), gridf, blockf, 0, s, a); }
   }
 }
 void launch_solve(const OdomArgs& a, hipStream_t s) {

@@ -101,16 +101,13 @@ __device__ __forceinline__ int ring_from_angle(float angle, int R) {
 // atan(t) / t on |t| <= 0.65, i.e. elevations up to 33 degrees; total error < 2e-5 degrees), and if the ring decision is the same
 // 2e-4 degrees below and above it — the decision is monotone in the angle — that IS the decision of the exact angle.  Otherwise
 // (0.1 % of the points, and anything steeper than 33 degrees) the exact f64 expression decides.
-#ifndef ALOAM_RING_F64_ONLY
-#define ALOAM_RING_F64_ONLY 0   // A/B builds: 1 = always the f64 expression (round 1)
-#endif
 __device__ __forceinline__ int ring_of(const float4& p, int R, int ring_from_field) {
   if (ring_from_field) {
     const int scanID = (int)p.w;
     return (scanID > R - 1 || scanID < 0) ? -1 : scanID;
   }
   const float s2 = p.x * p.x + p.y * p.y;
-  if (!ALOAM_RING_F64_ONLY) {
+  {
     const float t = p.z * __frsqrt_rn(s2), u = t * t;
     const float poly = 1.0f + u * (-0.3333319425582886f + u * (0.19994600117206573f + u * (-0.1420508623123169f + u * (0.10522426664829254f + u * (-0.06763934344053268f + u * 0.025188861414790154f)))));
     const float fast = t * poly * 57.29577951f;
@@ -282,25 +279,8 @@ __global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
 
 // -------------------------------------------------------------------------------------------------------
 // wave-wide max / min of a 32-bit value: DPP inside the rows of 16, v_readlane across the four rows (wave-uniform result)
-#ifndef ALOAM_RF_KEYS64
-#define ALOAM_RF_KEYS64 0       // A/B builds: 1 = always 64-bit run keys (round 1)
-#endif
-#ifndef ALOAM_RF_BUTTERFLY
-#define ALOAM_RF_BUTTERFLY 0    // A/B builds: 1 = the xor-butterfly reduction of round 1
-#endif
 template <bool MAX>
-__device__ __forceinline__ unsigned wave_extreme_u32(unsigned v, int lane) {
-  if (!ALOAM_RF_BUTTERFLY) return wave_reduce_u32<MAX>(v);
-  unsigned o;
-  o = xor_lane_u32<1>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
-  o = xor_lane_u32<2>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
-  o = xor_lane_u32<4>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
-  o = xor_lane_u32<8>(v, lane); v = MAX ? (o > v ? o : v) : (o < v ? o : v);
-  unsigned best = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
-#pragma unroll
-  for (int q = 1; q < 4; ++q) { const unsigned x = (unsigned)__builtin_amdgcn_readlane((int)v, 16 * q); best = MAX ? (x > best ? x : best) : (x < best ? x : best); }
-  return best;
-}
+__device__ __forceinline__ unsigned wave_extreme_u32(unsigned v, int lane) { (void)lane; return wave_reduce_u32<MAX>(v); }
 
 // ---- output offsets across the rings of a sweep --------------------------------------------------------------------------------
 // The four feature clouds are the ring-by-ring concatenation of what the ring workgroups produce (reference
@@ -475,97 +455,9 @@ __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, i
   if (lane == 0) { s_misc[1 + j] = ncorner | (count << 8); s_misc[8 + j] = (int)spill; }
 }
 
-// ---- stable radix sort of the 32-bit run keys of a ring on their voxel-index bits ------------------------------------------------
-// key = voxel index << EB | first element; the keys are generated in element order, so a STABLE sort on the voxel bits alone gives
-// the order the full-key sort gives.  8-bit digits, two or three passes (the voxel box of a ring has 2^14 .. 2^21 cells).  Every
-// thread keeps its keys in registers (wave w owns a contiguous, 64-aligned quarter of the keys; row k of a wave = 64 consecutive
-// keys), LDS is only the scatter target.  MEASURED AND NOT USED: against the LDS bitonic network it needs 9 instead of ~40 barriers
-// and about half the VALU instructions for the ~700 keys of a ring, yet k_ring_features as a whole ran 2.99 ms against 2.91 ms
-// (A/B on one box, two runs each, batch 1024): the sort is 7.5 us of the ~60 us a ring workgroup lives (device-timer build,
-// -DALOAM_RF_TIMING: curvature 10-15 us, reach 5, first-pass selection 20, redo + labels 1.5, voxel indices 3, run heads 2, sort
-// 7.5, voxel heads + gather 3, centroids 8), and the kernel is bound by the selection's VALU work.  Kept for A/B builds.
-#ifndef ALOAM_RF_RADIX
-#define ALOAM_RF_RADIX 0        // 1 = radix sort for the 32-bit run keys (k_vox_lds in the mapping stage uses the same scheme, where it pays)
-#endif
-template <int NPAD>
-__device__ __forceinline__ void radix_sort_run_keys(unsigned* keys, unsigned short* cntw, int* s_w, int n, int shift0, int key_bits, int tid) {
-  constexpr int NW = 4, RB = 8, NB = 1 << RB, EPT = NPAD / 256 + 1;
-  const int lane = tid & 63, wave = tid >> 6;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const int chunk = (((n + NW - 1) / NW) + 63) & ~63;
-  const int w0 = wave * chunk, w1 = min(n, w0 + chunk);
-  const int rows = __builtin_amdgcn_readfirstlane(w1 > w0 ? (w1 - w0 + 63) >> 6 : 0);       // <= EPT, wave-uniform
-  unsigned rk[EPT];
-  auto load = [&]() {
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) { const int p = w0 + k * 64 + lane; rk[k] = (k < rows && p < w1) ? keys[p] : 0xffffffffu; }
-  };
-  auto match = [&](unsigned d) {
-    unsigned long long m = ~0ull;
-#pragma unroll
-    for (int bit = 0; bit < RB; ++bit) { const bool one = (d >> bit) & 1u; const unsigned long long bal = __ballot(one); m &= one ? bal : ~bal; }
-    return m;
-  };
-  load();
-  __syncthreads();
-  for (int shift = shift0; shift < shift0 + key_bits; shift += RB) {
-    for (int c = tid; c < NB * NW; c += 256) cntw[c] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      if (k < rows) {
-        const bool live = w0 + k * 64 + lane < w1;                           // the tail of a wave's last row takes no part
-        const unsigned d = (rk[k] >> shift) & (NB - 1);
-        const unsigned long long m = match(d) & __ballot(live);
-        if (live && (m & lt) == 0ull) cntw[d * NW + wave] = (unsigned short)(cntw[d * NW + wave] + __popcll(m));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    {                                                                        // exclusive scan of the NB * NW counts, digit-major: 4 per thread
-      int v[4], sum = 0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { v[q] = cntw[tid * 4 + q]; sum += v[q]; }
-      const int inc = wave_scan_i32<false>(sum);
-      if (lane == 63) s_w[wave] = inc;
-      __syncthreads();
-      int run = inc - sum;
-      for (int w = 0; w < wave; ++w) run += s_w[w];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { cntw[tid * 4 + q] = (unsigned short)run; run += v[q]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      if (k < rows) {
-        const bool live = w0 + k * 64 + lane < w1;
-        unsigned key = rk[k];
-        asm volatile("" : "+v"(key));                                        // (no carrying of the histogram loop's bit tests across the scan)
-        const unsigned d = (key >> shift) & (NB - 1);
-        const unsigned long long m = match(d) & __ballot(live);
-        if (live) {
-          const int base = cntw[d * NW + wave];
-          keys[base + __popcll(m & lt)] = key;
-          if ((m & lt) == 0ull) cntw[d * NW + wave] = (unsigned short)(base + __popcll(m));
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();
-    if (shift + RB < shift0 + key_bits) { load(); __syncthreads(); }
-  }
-}
 
-#ifndef ALOAM_RF_CENTROID_AHEAD
-#define ALOAM_RF_CENTROID_AHEAD 0   // A/B builds: 1 = up to four members of a run loaded ahead (measured: 2.56 -> 2.62 ms, no gain: the phase is not latency-bound at seven workgroups per CU)
-#endif
 // markers in the generated code for tools/isa_phases.py (comments only: no instruction is emitted)
 #define ALOAM_PHASE(name) asm volatile("; ##PHASE " name)
-#ifdef ALOAM_RF_TIMING   // variant builds: one ring workgroup prints the duration of every phase (device timer, 10 ns units; each print itself costs ~130 us)
-#define RF_T(tag) do { __syncthreads(); if (blockIdx.x == 3 && blockIdx.y == 24 && threadIdx.x == 0) { const long long t_ = wall_clock64(); printf("k_ring_features phase %d : %d x10ns\n", tag, (int)(t_ - rf_t_prev)); rf_t_prev = wall_clock64(); } } while (0)
-#else
-#define RF_T(tag) do { } while (0)
-#endif
 // cloudLabel (2 sharp, 1 less sharp, 0, -1 flat) shares the per-point flag byte with the reach of the neighbour suppression: bits 0-1 hold the
 // label code (2, 1, 0, 3 = -1), bits 2-7 the reach during the selection and, afterwards, bit 2 the "continues the run of its predecessor" mark of
 // the voxel filter.  One byte array less per ring is what lets EIGHT ring workgroups share a CU's LDS (20.2 KB each) instead of seven.
@@ -576,7 +468,7 @@ __device__ __forceinline__ int label_of(unsigned char f) { const int c = f & 3; 
 template <int NPAD, typename K, int SHIFT>
 __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned char* flags, int* s_scan, int* s_misc,
                                                const float4* cloud, float4* out, int L, int tid, int lane, int wave,
-                                               unsigned long long* lb_lf, int ring, int nrings, unsigned epoch, int* err, int key_bits, long long& rf_t_prev) {
+                                               unsigned long long* lb_lf, int ring, int nrings, unsigned epoch, int* err) {
   const unsigned* vis = reinterpret_cast<const unsigned*>(smem);               // region A: voxel index per element [NPAD] ...
   K* rkeys = reinterpret_cast<K*>(smem);                                      // ... replaced by the run keys once the heads are known
   constexpr unsigned kEMask = SHIFT >= 32 ? 0xffffffffu : ((1u << (SHIFT & 31)) - 1u);
@@ -623,13 +515,10 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
   for (int it = 0; it < EIT; ++it)
     if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = (K)(((K)myvi[it] << SHIFT) | (K)e); }   // vis is dead: every thread read its share before the barrier
   __syncthreads();
-  RF_T(6); ALOAM_PHASE("after_run_heads");   // run heads + keys
-  if (ALOAM_RF_RADIX && sizeof(K) == 4)     // region A behind the keys is free by now: radix counters there, wave totals in s_scan
-    radix_sort_run_keys<NPAD>(reinterpret_cast<unsigned*>(smem), reinterpret_cast<unsigned short*>(smem + 4 * NPAD), s_scan + 128, n_runs, SHIFT & 31, key_bits, tid);
-  else
-    bitonic_sort_keys<K>(rkeys, n_runs, tid);
+  ALOAM_PHASE("after_run_heads");   // run heads + keys
+  bitonic_sort_keys<K>(rkeys, n_runs, tid);      // (a radix sort of the run keys - 9 instead of ~40 barriers, half the VALU work - was measured twice and lost, 2.48 against 2.43 ms: HISTORY.md)
 
-  RF_T(7); ALOAM_PHASE("after_sort");   // sort
+  ALOAM_PHASE("after_sort");   // sort
   // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count
   int n_vox = 0;
   unsigned vmask = 0;
@@ -665,7 +554,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
     if (lane == 0) { s_misc[40] = b0; s_misc[41] = b1; s_misc[42] = b2; s_misc[43] = b3; }
   }
   __syncthreads();
-  RF_T(8); ALOAM_PHASE("after_vox_heads_gather");   // voxel heads + gather of the counts in front
+  ALOAM_PHASE("after_vox_heads_gather");   // voxel heads + gather of the counts in front
   out += s_misc[43];
 #pragma unroll
   for (int it = 0; it < EIT; ++it) {
@@ -678,49 +567,25 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
       const K kq = rkeys[q];
       if ((unsigned)(kq >> SHIFT) != vi) break;
       int e = (int)((unsigned)kq & kEMask);
-#if ALOAM_RF_CENTROID_AHEAD
-      // up to four members of the run per round: how far the run goes comes from the flag bytes (LDS), so the four loads are independent of each
-      // other and in flight together instead of one dependent global load per member; the additions keep the input order
-      for (;;) {
-        const bool c1 = e + 1 < L && (flags[e + 6] & 4), c2 = c1 && e + 2 < L && (flags[e + 7] & 4), c3 = c2 && e + 3 < L && (flags[e + 8] & 4);
-        const float4 p0 = cloud[e + 5];
-        float4 p1 = p0, p2 = p0, p3 = p0;
-        if (c1) p1 = cloud[e + 6];
-        if (c2) p2 = cloud[e + 7];
-        if (c3) p3 = cloud[e + 8];
-        sx += p0.x; sy += p0.y; sz += p0.z; si += p0.w;
-        if (c1) { sx += p1.x; sy += p1.y; sz += p1.z; si += p1.w; }
-        if (c2) { sx += p2.x; sy += p2.y; sz += p2.z; si += p2.w; }
-        if (c3) { sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w; }
-        cnt += 1 + (int)c1 + (int)c2 + (int)c3;
-        e += 4;
-        if (!c3 || !(e < L && (flags[e + 5] & 4))) break;                            // the run stops at the next head or non-member
-      }
-#else
       do {
         const float4 pt = cloud[e + 5];
         sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
         ++cnt;
         ++e;
       } while (e < L && (flags[e + 5] & 4));                                  // the run stops at the next head or non-member
-#endif
     }
     const float fc = (float)cnt;
     out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
   }
-  RF_T(9); ALOAM_PHASE("after_centroids");   // centroids
+  ALOAM_PHASE("after_centroids");   // centroids
   return n_vox;
 }
 
-#ifndef ALOAM_RF_TICKET
-#define ALOAM_RF_TICKET 1       // A/B builds: 0 = ring from blockIdx.y (rounds 2 - 4: correct only while workgroups start in linear order)
-#endif
 template <int NPAD>
 __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   constexpr int MAXN = NPAD + 11;
   constexpr int ITEMS = (MAXN + 255) / 256;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // ring-major over the batch, see voxel_runs_tail
-#if ALOAM_RF_TICKET
   // the ring of this workgroup = the next ticket of its sweep (see "output offsets across the rings of a sweep" above)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_ticket[];
   int* s_ticket = reinterpret_cast<int*>(smem_ticket);                       // first word of the dynamic LDS, free again after the barrier
@@ -731,9 +596,10 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   asm volatile("" : "+s"(r_));                                               // a scalar register from here on, like blockIdx.y was
   const int r = r_;
   __syncthreads();
-#else
-  const int r = blockIdx.y;
-#endif
+  if (r >= a.R) {                                                           // more tickets than rings: the counter was not reset (k_cloud_sizes of an earlier launch never ran)
+    if (tid == 0) atomicOr(&a.meta[b].err, kErrInternal);
+    return;
+  }
   const int start = a.ringstart[b * (a.R + 1) + r];
   const int n = a.ringstart[b * (a.R + 1) + r + 1] - start;
   unsigned long long* lb = a.lookback + (long long)b * 4 * a.R;             // [class][ring] count granules of this sweep
@@ -743,7 +609,6 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     return;
   }
 
-  long long rf_t_prev = wall_clock64();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // region A (aliased over time): two 266-point xyz tiles during the curvature pass, then the curvature per point, then the voxel
   // index per element, then the run keys.  Keeping it at 8 * NPAD bytes is what lets seven workgroups share a CU's LDS.
@@ -842,7 +707,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     __syncthreads();
   }
 
-  RF_T(1); ALOAM_PHASE("after_curvature");   // curvature
+  ALOAM_PHASE("after_curvature");   // curvature
   // reach of the neighbour suppression around every point: a pick of i marks i+1 .. i+fw and i-1 .. i-bk (runs of consecutive
   // gap-free steps, at most 5; :316-341).  Packed into the flag byte: bits 2-4 fw, bits 5-7 bk.  The curvature tiles are retired
   // (the loop above ends with a barrier), so region A takes the curvature per local point in the same pass.
@@ -864,7 +729,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   }
   __syncthreads();
 
-  RF_T(2); ALOAM_PHASE("after_reach");   // reach + curvature array
+  ALOAM_PHASE("after_reach");   // reach + curvature array
   // ---- corner / flat selection (:284-390): every sector by its own wave, speculatively without the marks the previous
   // sectors leave on its first five points; those marks only matter if the sector picked one of the marked points, which
   // the second pass detects (and then redoes that sector with the marks) in sector order
@@ -872,7 +737,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
 #pragma unroll 1
   for (int j = __builtin_amdgcn_readfirstlane(wave); j < kSectors; j += 4) pick_sector<K6>(j, 0u, L, lane, curv_l, flags, s_pick, s_misc);   // j in an SGPR: sector bounds, pick positions and spill marks are scalar work
   __syncthreads();
-  RF_T(3); ALOAM_PHASE("after_select1");   // first-pass selection
+  ALOAM_PHASE("after_select1");   // first-pass selection
   if (wave == 0) {
     unsigned carry = (unsigned)s_misc[8];                                    // marks on the (up to 5) points after sector 0
 #pragma unroll 1
@@ -920,7 +785,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     }
   }
 
-  RF_T(4); ALOAM_PHASE("after_redo_labels_counts");   // redo, labels, counts
+  ALOAM_PHASE("after_redo_labels_counts");   // redo, labels, counts
   // ---- labels out (parity tests only) and less-flat membership: local 5 .. n-7 with label <= 0 (:392-398)
   if (a.store_debug) for (int i = tid; i < n; i += 256) a.label[(long long)b * a.cap + start + i] = (int8_t)label_of(flags[i]);
 
@@ -1025,17 +890,16 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     }
   }
   __syncthreads();
-  RF_T(5); ALOAM_PHASE("after_bbox_voxidx");   // bounding box + voxel indices
+  ALOAM_PHASE("after_bbox_voxidx");   // bounding box + voxel indices
   // 32-bit run keys (voxel index << EB | first element) whenever the voxel box is small enough — most rings: half the LDS
   // traffic and a third fewer VALU instructions in the sort; the 64-bit keys remain for rings whose box has more cells.
   constexpr int EB = NPAD <= 2048 ? 11 : 12;                                  // bits of an element index
   float4* out = a.less_flat + (long long)b * a.cap;                          // final place: offset = less-flat points of the rings in front
-  if (!ALOAM_RF_KEYS64 && (overflow || cells_in_box <= (1ll << (32 - EB)))) {
+  if (overflow || cells_in_box <= (1ll << (32 - EB))) {
     // bits of a voxel index: every index is below cells_in_box (or, in PCL's overflow case, the element number itself)
-    const int key_bits = overflow ? EB : (cells_in_box > 1 ? 64 - __clzll(cells_in_box - 1) : 1);
-    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err, key_bits, rf_t_prev);
+    voxel_runs_tail<NPAD, unsigned, EB>(smem, flags, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err);
   } else
-    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err, 0, rf_t_prev);
+    voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err);
   // the picked points go straight to their final place in the three clouds, in the reference's order (ring, sector, pick order;
   // sharp = the first two less-sharp picks, :301-311)
   if (wave == 0) {
@@ -1079,10 +943,7 @@ void launch_classify(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_cla
 void launch_ring_offsets(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ring_offsets, dim3(a.B), dim3(1024), 0, s, a); }
 void launch_scatter(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_scatter, dim3(a.NB, a.B), dim3(256), 0, s, a); }
 void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s) {
-#ifndef ALOAM_RF_DEBUG_LDS
-#define ALOAM_RF_DEBUG_LDS 0        // occupancy experiments: extra dynamic LDS bytes per ring workgroup, used by nothing
-#endif
-  const size_t lds = ring_features_lds_bytes(npad) + ALOAM_RF_DEBUG_LDS;
+  const size_t lds = ring_features_lds_bytes(npad);
   if (npad <= 2048) hipLaunchKernelGGL(k_ring_features<2048>, dim3(a.B, a.R), dim3(256), lds, s, a, leaf);
   else hipLaunchKernelGGL(k_ring_features<4096>, dim3(a.B, a.R), dim3(256), lds, s, a, leaf);
   hipLaunchKernelGGL(k_cloud_sizes, dim3(a.B), dim3(64), 0, s, a);

@@ -316,6 +316,7 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
   std::vector<double> r, J;
   double cost = pb.evaluate(q, t, &r, &J);
   sm.initial_cost = cost;
+  const double q_entry[4] = {q[0], q[1], q[2], q[3]}, t_entry[3] = {t[0], t[1], t[2]};   // ceres::Solve puts these back after a FAILURE (solution not usable)
   // Ceres' ResidualBlock::Evaluate rejects non-finite residuals / Jacobians: "Residual and Jacobian evaluation failed" -> FAILURE
   // before the first iteration, parameters untouched (e.g. LidarEdgeFactor with a == b: 0 * inf).
   bool jac_finite = true;
@@ -422,7 +423,7 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
       // HandleSuccessfulStep(): x is the candidate now; if residuals / Jacobian cannot be evaluated there the solve ends as FAILURE
       bool jf = std::isfinite(cost);
       for (double v : J) jf = jf && std::isfinite(v);
-      if (!jf) { sm.successful++; sm.termination = 5; break; }
+      if (!jf) { sm.termination = 5; break; }
       gmax = gradient_max(J, r);
       apply_scale(J);
       sm.successful++;
@@ -435,6 +436,11 @@ LmSummary lm_solve(const std::vector<EdgeRec>& edges, const std::vector<PlaneRec
       decrease_factor *= 2.0;
       reuse_diagonal = true;
     }
+  }
+  if (sm.termination == 5) {                            // FAILURE (invalid steps / Jacobian at an accepted point): parameters as at entry, Solver::Summary::IsSolutionUsable()
+    for (int k = 0; k < 4; ++k) q[k] = q_entry[k];
+    for (int k = 0; k < 3; ++k) t[k] = t_entry[k];
+    cost = sm.initial_cost;
   }
   sm.final_cost = cost;
   return sm;

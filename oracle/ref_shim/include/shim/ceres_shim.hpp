@@ -322,6 +322,7 @@ inline void Solve(const Solver::Options& o, Problem* problem, Solver::Summary* s
   const int n = ev.n_local, m = ev.n_rows;
   std::vector<double> x, xc, r, J;
   ev.get(&x);
+  const std::vector<double> x_entry = x;        // solver.cc Minimize(): a solution that is not usable (FAILURE) is replaced by the original parameters
   double cost = 0.0;
   *sum = Solver::Summary();
   if (m == 0) { sum->shim_termination = 4; sum->termination_type = CONVERGENCE; return; }
@@ -392,12 +393,12 @@ inline void Solve(const Solver::Options& o, Problem* problem, Solver::Summary* s
     if (rel > o.min_relative_decrease) {
       x = xc; x_norm = norm_of(x);
       ev.evaluate(x, &cost, &r, &J);
-      ++sum->num_successful_steps;
-      {   // HandleSuccessfulStep(): residuals / Jacobian must evaluate at the accepted point, else FAILURE
+      {   // HandleSuccessfulStep(): residuals / Jacobian must evaluate at the accepted point, else FAILURE (the step is not counted)
         bool jf = std::isfinite(cost);
         for (double v : J) jf = jf && std::isfinite(v);
         if (!jf) { term = 5; break; }
       }
+      ++sum->num_successful_steps;
       gmax = grad_max();
       scale_jac();
       const double c3 = 2.0 * rel - 1.0;
@@ -408,6 +409,7 @@ inline void Solve(const Solver::Options& o, Problem* problem, Solver::Summary* s
       radius /= decrease; decrease *= 2.0;
     }
   }
+  if (term == 5) { x = x_entry; cost = sum->initial_cost; }   // Summary::IsSolutionUsable() is false: the user's parameter blocks keep their entry values
   for (size_t i = 0; i < problem->blocks_.size(); ++i) for (int k = 0; k < problem->blocks_[i].size; ++k) problem->blocks_[i].values[k] = x[ev.global_off[i] + k];
   sum->final_cost = cost; sum->iterations = iter; sum->shim_termination = term;
   sum->termination_type = (term == 0) ? NO_CONVERGENCE : (term == 5 ? FAILURE : CONVERGENCE);

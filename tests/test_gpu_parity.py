@@ -524,6 +524,34 @@ def test_stage_sized_contexts(O, binding, sequence):
         c.close()
 
 
+def test_two_hundred_contexts_created_and_destroyed(binding, sequence):
+    """Round 5 saw one GPU memory fault in the first aloam_create of a process on one of five fresh boxes and never found a cause.  This hammers
+    the path it was on: 200 contexts of every stage mask, mapping enabled where the mask has it (allocation + zero-fill of every buffer + the
+    state uploads, then aloam_synchronize, which surfaces device-side faults), a sweep through every 20th, and a handful alive at once."""
+    scans, R, t, model = sequence("VLP-16", 2, seed=3, columns=600)
+    masks = [binding.STAGE_ALL, binding.STAGE_REGISTRATION, binding.STAGE_ODOMETRY, binding.STAGE_MAPPING, binding.STAGE_REGISTRATION | binding.STAGE_ODOMETRY,
+             binding.STAGE_ODOMETRY | binding.STAGE_MAPPING]
+    alive = []
+    for i in range(200):
+        stages = masks[i % len(masks)]
+        gpu = binding.Aloam(n_scans=16, min_range=0.3, batch=1 + i % 3, max_points=20000 + 512 * (i % 5), stages=stages)
+        if stages & binding.STAGE_MAPPING:
+            gpu.mapping_enable(0.2, 0.4, pool_points=4096 << (i % 4))
+        gpu.synchronize()
+        if stages == binding.STAGE_ALL and i % 20 == 0:
+            for x in scans:
+                gpu.scan_register([x] * gpu.batch)
+                gpu.odometry_step()
+                gpu.mapping_step()
+            gpu.synchronize()
+            assert gpu.map_info()["frame_count"] == 2
+        alive.append(gpu)
+        if len(alive) > 4:
+            alive.pop(0).close()
+    for gpu in alive:
+        gpu.close()
+
+
 def test_lm_branch_coverage(O, binding, sequence):
     """The device trust-region loop (lm_device.hpp; reference call src/laserOdometry.cpp:494-499) against the oracle on problems
     built to leave the happy path (tests/lm_scenarios.py): bad warm starts, unobservable directions, fewer residual rows than

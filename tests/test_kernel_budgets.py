@@ -48,12 +48,12 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 def test_ring_features_keeps_seven_workgroups_per_cu(registration):
     k = registration["k_ring_features<2048>"]
-    # seven workgroups per CU = seven waves per SIMD: <= 72 registers.  (61 in round 4; the ring ticket's global atomic at the top of the
-    # kernel makes the compiler schedule for a lower occupancy target — 72 — whatever the ticket is used for; forcing 64 spills ten
-    # registers.  Seven against eight workgroups per CU was measured equal in round 4, and ticket against blockIdx.y in round 5.)
-    assert k[".vgpr_count"] <= 72 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
-    k = registration["k_ring_features<4096>"]                                  # the long-ring class: 38 KB of LDS, four workgroups per CU = four waves per SIMD
-    assert k[".vgpr_count"] <= 128 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
+    # eight waves per SIMD: <= 64 registers (61 measured; seven workgroups per CU is what its 22 KB of LDS allow).  Round 5's ticket atomic had
+    # taken it to 72; the early return on a ticket beyond the last ring brought the 61 of round 4 back.  Pinned near the measured value so
+    # that a regression shows.
+    assert k[".vgpr_count"] <= 64 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
+    k = registration["k_ring_features<4096>"]                                  # the long-ring class: 38 KB of LDS, four workgroups per CU = four waves per SIMD; 76 measured
+    assert k[".vgpr_count"] <= 80 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
     for name in ("k_classify", "k_scatter", "k_find_ends", "k_ring_offsets"):
         k = registration[name]
         assert k[".vgpr_count"] <= 64 and k[".vgpr_spill_count"] == 0 and k[".sgpr_spill_count"] == 0, (name, k)
@@ -61,17 +61,14 @@ def test_ring_features_keeps_seven_workgroups_per_cu(registration):
 
 def test_association_waves_fit_eight_per_simd(odometry):
     """Round 4: two queries per wave (k_associate_pair).  The corner class fits eight waves per SIMD (<= 64 VGPRs), the planar class seven
-    (<= 72: six kept rows of 32 candidates per half; forcing 64 spills 8 registers); 128-ring sensors keep eight rows (<= 80).  The one-query
-    kernels of rounds 1-3 stay as A/B builds (ALOAM_ASSOC_PAIR=0) with their old budgets; the flagged-sequence fallback only must not spill."""
+    (<= 72: six kept rows of 32 candidates per half; forcing 64 spills 8 registers); 128-ring sensors keep eight rows (<= 80).  The nearly-sorted
+    form (k_associate_nearly, round 6) and the flagged-sequence fallback only must not spill: they serve a handful of sequences per step."""
     limits = {"k_associate_pair<false, false>": 64, "k_associate_pair<true, false>": 72, "k_associate_pair<false, true>": 72, "k_associate_pair<true, true>": 80}
     for name, lim in limits.items():
         k = odometry[name]
         assert k[".vgpr_count"] <= lim and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, (name, k)
         assert k[".group_segment_fixed_size"] <= 1024, (name, k)               # mark slots + rank table: half a KiB per wave
     for name, k in odometry.items():
-        if name.startswith("k_associate<"):
-            wide_plane = name == "k_associate<true, false, true>"               # 128-ring sensors: six candidate rows in flight, 80 VGPRs by design
-            assert k[".vgpr_count"] <= (80 if wide_plane else 64), (name, k)
         if name.startswith("k_associate"):
             assert k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, (name, k)
     assert odometry["k_build_grids_fused"][".vgpr_count"] <= 64
@@ -87,7 +84,7 @@ def test_solvers_hold_their_state_in_registers(odometry, mapping):
 def test_mapping_search_and_filters(mapping):
     for name in ("k_map_search<0>", "k_map_search<1>"):
         k = mapping[name]
-        assert k[".vgpr_count"] <= 72 and k[".vgpr_spill_count"] == 0, (name, k)   # round 5: packed (distance, index) keys + positions: 63 / 65 registers, 7 - 8 waves per SIMD (72 / 74 before)
+        assert k[".vgpr_count"] <= 66 and k[".vgpr_spill_count"] == 0, (name, k)   # round 5: packed (distance, index) keys + positions: 63 / 65 registers (72 / 74 before)
     # the LDS voxel filter keeps its keys in registers; the 1024-thread instance is capped at 128 VGPRs by its workgroup size and is
     # allowed the handful of spilled registers it has today, not more
     big = mapping["k_vox_lds<1024, 24576, 65536>"]
