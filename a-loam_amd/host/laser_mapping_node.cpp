@@ -180,9 +180,9 @@ int main(int argc, char** argv) {
   float lineRes = 0, planeRes = 0;
   nh.param<float>("mapping_line_resolution", lineRes, 0.4);
   nh.param<float>("mapping_plane_resolution", planeRes, 0.8);
-  int n_scans = 64, pool_points = 1 << 20;
+  int n_scans = 64, pool_points = 1 << 17;
   nh.param<int>("scan_line", n_scans, 64);
-  nh.param<int>("map_pool_points", pool_points, 1 << 20);  // device-resident map capacity per feature class
+  nh.param<int>("map_pool_points", pool_points, 1 << 17);  // where the device-resident map starts (points per feature class); it doubles as the map grows, like the reference's std::vector cubes
   printf("line resolution %f plane resolution %f \n", lineRes, planeRes);
 
   aloam_config cfg;

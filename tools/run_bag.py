@@ -83,7 +83,7 @@ def main():
     binding = importlib.import_module("a-loam_amd.binding")
     gpu = binding.Aloam(n_scans=args.scan_line, min_range=args.minimum_range, max_points=400000)
     if args.mapping:
-        gpu.mapping_enable(args.line_res, args.plane_res, pool_points=1 << 21)
+        gpu.mapping_enable(args.line_res, args.plane_res, pool_points=1 << 17)   # grows with the map
     odo, mapped = [], []
     for k, (stamp, xyz) in enumerate(sweeps(args.bag, args.topic)):
         if args.max_frames and k >= args.max_frames:

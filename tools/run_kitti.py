@@ -83,7 +83,7 @@ def main():
     # launch/aloam_velodyne_HDL_64.launch: scan_line 64, minimum_range 5, mapping resolutions 0.4 / 0.8
     gpu = binding.Aloam(n_scans=64, min_range=5.0, max_points=140000, distortion=args.distortion)
     if args.mapping:
-        gpu.mapping_enable(0.4, 0.8, pool_points=1 << 21)
+        gpu.mapping_enable(0.4, 0.8, pool_points=1 << 17)          # where the map starts: the pools double as it grows (src/laserMapping.cpp:737-783 push_back)
     os.makedirs(args.out, exist_ok=True)
     odo, mapped = [], []
     for k, stamp in enumerate(times):
