@@ -477,6 +477,7 @@ def cpu_baseline(args, wl, rank):
     outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
     wall = time.perf_counter() - t0
     rate_all = sum(o["scans"] / o["seconds"] for o in outs)
+    ref_code = reference_code_baseline(host, wl, order)
     try:
         for f in os.listdir(tmp):
             os.remove(os.path.join(tmp, f))
@@ -487,7 +488,32 @@ def cpu_baseline(args, wl, rank):
             "ms_per_scan_median": round(float(np.median(per)), 3), "ms_per_scan_p95": round(float(np.percentile(per, 95)), 3),
             "sample": f"{one['scans']} sweeps of one synthetic {wl.sensor} sequence ({args.cpu_seconds:.0f} s), oracle/ (kd-tree NN, dual-number autodiff, dense QR LM), 1 thread",
             "all_cores": {"value": round(rate_all, 2), "unit": "scans/s", "cores": cores, "kind": "port",
-                          "sample": f"{cores} processes x {args.cpu_seconds:.0f} s, one independent sequence per core (same sweeps), {sum(o['scans'] for o in outs)} sweeps, wall {wall:.1f} s"}}
+                          "sample": f"{cores} processes x {args.cpu_seconds:.0f} s, one independent sequence per core (same sweeps), {sum(o['scans'] for o in outs)} sweeps, wall {wall:.1f} s"},
+            "reference_code": ref_code}
+
+
+def reference_code_baseline(host, wl, order, sweeps=120):
+    """The reference's OWN translation units (oracle/_ref: src/scanRegistration.cpp and src/laserOdometry.cpp + src/lidarFactor.hpp compiled where they lie,
+    prebuilt in the container that has /root/reference; they travel to the GPU box as binaries) on the same sweeps, one thread: seconds inside the
+    reference's callback / main-loop body, the drivers' file I/O excluded.  Their third-party calls (PCL VoxelGrid / KdTreeFLANN, Ceres Solve with its
+    autodiff, Eigen) resolve to this repo's stand-in headers - the real libraries are not in the image - so this prices the reference's first-party code
+    on stand-in third-party code, which is why `cpu_baseline.kind` stays "port" and this is reported beside it."""
+    try:
+        import ref_py
+        if not ref_py.available():
+            return None
+        xs = [host[k, : wl.counts[0, k]] for k in (order * (sweeps // len(order) + 1))[:sweeps]]
+        reg = ref_py.scan_registration(xs, wl.model.n_scans, wl.model.min_range, timing=True)
+        ref_py.laser_odometry(reg, timing=True)
+        t_reg, t_odo = ref_py.LAST_TIMING.get("scan_registration"), ref_py.LAST_TIMING.get("laser_odometry")
+        if not t_reg or not t_odo:
+            return None
+        return {"value": round(len(xs) / (t_reg + t_odo), 3), "unit": "scans/s", "cores": 1, "kind": "reference",
+                "ms_per_scan": {"scan_registration": round(1e3 * t_reg / len(xs), 3), "laser_odometry": round(1e3 * t_odo / len(xs), 3)},
+                "sample": f"{len(xs)} sweeps of one synthetic {wl.sensor} sequence through oracle/_ref (the reference's scanRegistration.cpp + laserOdometry.cpp, one thread, "
+                          "the two nodes one after the other); third-party calls on this repo's stand-in PCL / Ceres / Eigen headers"}
+    except Exception as e:      # the baseline legs never take the bench line down
+        return {"error": str(e)[:200]}
 
 
 def _rotate(q, v):

@@ -62,7 +62,18 @@ class _Reader:
         return self.o == len(self.b)
 
 
-def scan_registration(scans, n_scans, min_range, exe=None):
+def _timing(stderr):
+    """`REF_TIMING <stage> frames <n> seconds <s>` lines of a driver run with REF_TIMING=1 -> seconds inside the reference's own code."""
+    for line in stderr.splitlines():
+        if line.startswith("REF_TIMING"):
+            return float(line.split()[-1])
+    return None
+
+
+LAST_TIMING = {}     # stage -> seconds the reference's own code spent in the last timed run (timing=True)
+
+
+def scan_registration(scans, n_scans, min_range, exe=None, timing=False):
     """scans: list of (n, 4) float32 arrays -> list of dicts with the five published clouds + curvature / label / picked."""
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
@@ -71,7 +82,9 @@ def scan_registration(scans, n_scans, min_range, exe=None):
             for s in scans:
                 _write_cloud(f, s)
         r = subprocess.run([exe or os.path.join(REF_DIR, "ref_scan_registration"), str(int(n_scans)), repr(float(min_range)), fin, fout],
-                           capture_output=True, text=True)
+                           capture_output=True, text=True, env=dict(os.environ, REF_TIMING="1") if timing else None)
+        if timing:
+            LAST_TIMING["scan_registration"] = _timing(r.stderr)
         if r.returncode != 0:
             raise RuntimeError(f"ref_scan_registration failed ({r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
         rd = _Reader(fout)
@@ -87,7 +100,7 @@ def scan_registration(scans, n_scans, min_range, exe=None):
         return out
 
 
-def laser_odometry(frames, exe=None, exe_args=()):
+def laser_odometry(frames, exe=None, exe_args=(), timing=False):
     """frames: list of dicts with sharp / less_sharp / flat / less_flat / cloud -> list of dicts (q_w, t_w, q_lc, t_lc,
     corner_corr, plane_corr, corner_last, surf_last), one per frame, from ONE run of the node (state carries over)."""
     with tempfile.TemporaryDirectory() as d:
@@ -97,7 +110,10 @@ def laser_odometry(frames, exe=None, exe_args=()):
             for fr in frames:
                 for k in ("sharp", "less_sharp", "flat", "less_flat", "cloud"):
                     _write_cloud(f, fr[k])
-        r = subprocess.run([exe or os.path.join(REF_DIR, "ref_laser_odometry"), *[str(a) for a in exe_args], fin, fout], capture_output=True, text=True)
+        r = subprocess.run([exe or os.path.join(REF_DIR, "ref_laser_odometry"), *[str(a) for a in exe_args], fin, fout], capture_output=True, text=True,
+                           env=dict(os.environ, REF_TIMING="1") if timing else None)
+        if timing:
+            LAST_TIMING["laser_odometry"] = _timing(r.stderr)
         if r.returncode != 0:
             raise RuntimeError(f"ref_laser_odometry failed ({r.returncode}):\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
         rd = _Reader(fout)

@@ -9,6 +9,8 @@
 //        correspondences of the frame's LAST ceres::Solve: int32 n_edge, n_plane, n_edge x 9 float64 (curr_point, last_point_a,
 //        last_point_b of every LidarEdgeFactor the reference created, :365-381), n_plane x 12 float64 (curr_point, last_point_j, l, m
 //        of every LidarPlaneFactor, :460-479) — read off the functors inside the residual blocks, the reference's source untouched
+#include <chrono>
+
 #include "ref_io.hpp"
 #include "lidarFactor.hpp"                                                    // the reference's own header (struct members are public)
 
@@ -60,16 +62,30 @@ int main(int argc, char** argv) {
       ++flushed;
     }
   };
-  ref_shim::ok_hook() = [&]() { flush(); return flushed < n_frames; };
+  // REF_TIMING=1: time the node spends between the delivery of a frame's five messages and its next ros::ok(): the body of its main loop
+  // (association, ceres::Solve, the publishers), without this driver's file reads and result write-out
+  double loop_s = 0.0;
+  bool running = false;
+  std::chrono::steady_clock::time_point t_frame;
+  ref_shim::ok_hook() = [&]() {
+    if (running) { loop_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_frame).count(); running = false; }
+    flush();
+    return flushed < n_frames;
+  };
   ref_shim::spin_hook() = [&]() {                                             // ros::spinOnce(): one synchronised frame per turn
     if (delivered >= n_frames) return;
     const double stamp = 0.1 * delivered;
     const char* topics[5] = {"/laser_cloud_sharp", "/laser_cloud_less_sharp", "/laser_cloud_flat", "/laser_cloud_less_flat", "/velodyne_cloud_2"};
-    for (const char* t : topics) ref_shim::deliver(t, ref_io::make_msg(ref_io::read_cloud(fin), stamp));
+    sensor_msgs::PointCloud2 msgs[5];
+    for (int k = 0; k < 5; ++k) msgs[k] = ref_io::make_msg(ref_io::read_cloud(fin), stamp);
+    t_frame = std::chrono::steady_clock::now();
+    running = true;
+    for (int k = 0; k < 5; ++k) ref_shim::deliver(topics[k], msgs[k]);
     ++delivered;
   };
   ref_node_main(argc, argv);
   flush();
   std::fclose(fout);
+  if (std::getenv("REF_TIMING")) std::fprintf(stderr, "REF_TIMING laser_odometry frames %d seconds %.6f\n", delivered, loop_s);
   return 0;
 }

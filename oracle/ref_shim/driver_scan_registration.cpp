@@ -5,6 +5,7 @@
 //   in : int32 n_frames, then per frame one cloud record (x, y, z, ignored)
 //   out: per frame the five published clouds (/velodyne_cloud_2, /laser_cloud_sharp, /laser_cloud_less_sharp,
 //        /laser_cloud_flat, /laser_cloud_less_flat) followed by int32 n + n x (float curvature, int32 label, int32 picked)
+#include <chrono>
 #include <cmath>
 
 #include "ref_io.hpp"
@@ -23,6 +24,7 @@ int main(int argc, char** argv) {
   ref_io::must(fin && fout, "cannot open files");
   const int n_frames = ref_io::read_i32(fin);
   int frame = 0;
+  double handler_s = 0.0;                                                     // time inside the reference's callback (REF_TIMING=1 prints it)
   const char* topics[5] = {"/velodyne_cloud_2", "/laser_cloud_sharp", "/laser_cloud_less_sharp", "/laser_cloud_flat", "/laser_cloud_less_flat"};
   ref_shim::ok_hook() = [&]() { return frame < n_frames; };
   ref_shim::spin_hook() = [&]() {                                             // ros::spin() -> one /velodyne_points message per turn
@@ -30,7 +32,9 @@ int main(int argc, char** argv) {
     bool dense = true;
     for (float x : v) dense = dense && std::isfinite(x);
     sensor_msgs::PointCloud2 msg = ref_io::make_msg(v, 0.1 * frame, dense);
-    ref_shim::deliver("/velodyne_points", msg);
+    const auto t0 = std::chrono::steady_clock::now();
+    ref_shim::deliver("/velodyne_points", msg);                              // laserCloudHandler runs inside: conversion, selection, the five toROSMsg + publish
+    handler_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     auto& pub = ref_shim::published<sensor_msgs::PointCloud2>();
     for (const char* t : topics) {
       ref_io::must(pub[t].size() == static_cast<size_t>(frame) + 1, "the node did not publish one message per sweep");
@@ -48,5 +52,6 @@ int main(int argc, char** argv) {
   };
   ref_node_main(argc, argv);
   std::fclose(fout);
+  if (std::getenv("REF_TIMING")) std::fprintf(stderr, "REF_TIMING scan_registration frames %d seconds %.6f\n", frame, handler_s);
   return 0;
 }
