@@ -87,6 +87,7 @@ def lib():
         L.aloam_last_error.argtypes = [vp]; L.aloam_last_error.restype = C.c_char_p
         L.aloam_stream.argtypes = [vp]; L.aloam_stream.restype = vp
         L.aloam_synchronize.argtypes = [vp]
+        L.aloam_set_voxel_sum_order.argtypes = [vp, C.c_int]
         L.aloam_scan_register.argtypes = [vp, C.POINTER(vp), ip, C.c_int]
         L.aloam_scan_register_device.argtypes = [vp, vp, C.c_longlong, ip, C.c_int]
         L.aloam_scan_register_host.argtypes = [vp, vp, C.c_longlong, ip, C.c_int]
@@ -162,6 +163,10 @@ class Aloam:
                 L.aloam_destroy(h)
             self.h = None
             raise AloamError(rc, msg)
+
+    def set_voxel_sum_order(self, reference_order=True):
+        """True: pcl::VoxelGrid's own summation order (libstdc++ std::sort replayed; validation mode); False: input order (default)."""
+        self._check(lib().aloam_set_voxel_sum_order(self.h, 1 if reference_order else 0))
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None:

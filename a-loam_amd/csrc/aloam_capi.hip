@@ -92,6 +92,7 @@ struct aloam_ctx {
   VoxSeg* d_segs = nullptr; int *d_tile_seg = nullptr, *d_tile_heads = nullptr, *d_tile_pref = nullptr, *d_vox_counters = nullptr, *d_bbox = nullptr;
   unsigned long long* d_keys[2] = {nullptr, nullptr}; float4* d_voxtmp = nullptr;
   bool system_inited = false;        // reference src/laserOdometry.cpp:69
+  int sum_order = 0;                 // ALOAM_SUM_INPUT_ORDER / ALOAM_SUM_REFERENCE_ORDER (aloam_set_voxel_sum_order)
   // small batches (the ROS shims run batch 1): the ~15 dependent launches of an odometry step as ONE hipGraph launch per buffer parity
   hipGraphExec_t odom_graph[2] = {nullptr, nullptr};
   bool use_graph = false;            // batch <= ALOAM_GRAPH_MAX_BATCH (environment, default 0 = off), read once at creation
@@ -238,7 +239,7 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   HIP_TRY(c, hipMemcpyAsync(c->d_nin, nin_slot, sizeof(int) * c->B, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->nin_done[ns], c->stream));
   c->nin_used[ns] = true;
-  c->debug_arrays = debug_arrays;
+  c->debug_arrays = debug_arrays || c->sum_order != 0;      // the reference-order pass reads cloudLabel
   if (++c->reg_epoch == 0) c->reg_epoch = 1;
   const RegArgs a = reg_args(c, d_scans, seq_stride, stride_bytes);
   { ProfScope p(c, K_FIND_ENDS); launch_find_ends(a, c->d_nin, c->stream); }
@@ -246,7 +247,8 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   { ProfScope p(c, K_RING_OFFSETS); launch_ring_offsets(a, c->stream); }
   { ProfScope p(c, K_SCATTER); launch_scatter(a, c->stream); }
   if (slot >= 0) { HIP_TRY(c, hipEventRecord(c->in_consumed[slot], c->stream)); c->in_used[slot] = true; }   // the raw sweep is not read after this
-  { ProfScope p(c, K_RING_FEATURES); launch_ring_features(a, c->npad, 0.2f, c->stream); }   // leaf 0.2 (src/scanRegistration.cpp:404)
+  { ProfScope p(c, K_RING_FEATURES); launch_ring_features(a, c->npad, 0.2f, c->stream);     // leaf 0.2 (src/scanRegistration.cpp:404)
+    if (c->sum_order) launch_less_flat_reference_order(reg_args(c, d_scans, seq_stride, stride_bytes), 0.2f, c->stream); }
   HIP_TRY(c, hipGetLastError());
   c->have_features = true;
   return ALOAM_OK;
@@ -1053,6 +1055,16 @@ int aloam_mapping_enable(aloam_ctx* c, float line_res, float plane_res, int pool
   return ALOAM_OK;
 }
 
+int aloam_set_voxel_sum_order(aloam_ctx* c, int order) {
+  DeviceScope device_scope(c);
+  if (!c) return ALOAM_E_ARG;
+  if (order != ALOAM_SUM_INPUT_ORDER && order != ALOAM_SUM_REFERENCE_ORDER) { c->err = "unknown summation order"; return ALOAM_E_ARG; }
+  if (order == ALOAM_SUM_REFERENCE_ORDER && prepare_reference_order()) { c->err = "k_vox_reference_order: dynamic LDS size rejected"; return ALOAM_E_HIP; }
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->sum_order = order;
+  return ALOAM_OK;
+}
+
 int aloam_mapping_set_pool_limit(aloam_ctx* c, int max_pool_points) {
   if (!c) return ALOAM_E_ARG;
   if (max_pool_points < 4096 || max_pool_points > (1 << 26)) { c->err = "bad pool limit (4096 .. 2^26 points)"; return ALOAM_E_ARG; }
@@ -1085,7 +1097,8 @@ int aloam_mapping_step(aloam_ctx* c) {
     const VoxArgs v = vox_args(c, c->B * 2, c->map_levels);
     HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 4 * sizeof(int), c->stream));   // general-path count, the two LDS-filter lists
     launch_map_stack_segments(a, v, c->stream);
-    launch_voxel_filter(v, c->map_tile_bound[0], c->stream); }
+    if (c->sum_order) launch_voxel_filter_reference_order(v, a, true, c->stream);
+    else launch_voxel_filter(v, c->map_tile_bound[0], c->stream); }
   { ProfScope p(c, K_MAP_GRID); launch_map_grid(a, c->stream); }            // kdtree*FromMap->setInputCloud (:558-559)
   for (int iter = 0; iter < 2; ++iter) {                                    // :562
     { ProfScope p(c, K_MAP_ASSOC); launch_map_associate(a, iter, c->stream); }
@@ -1096,7 +1109,8 @@ int aloam_mapping_step(aloam_ctx* c) {
     const VoxArgs v = vox_args(c, c->B * 2 * kMapValidMax, c->map_cube_levels);
     HIP_TRY(c, hipMemsetAsync(c->d_vox_counters + 4, 0, 4 * sizeof(int), c->stream));
     launch_map_cube_segments(a, v, c->stream);
-    launch_voxel_filter(v, c->map_tile_bound[1], c->stream); }
+    if (c->sum_order) launch_voxel_filter_reference_order(v, a, false, c->stream);
+    else launch_voxel_filter(v, c->map_tile_bound[1], c->stream); }
   { ProfScope p(c, K_MAP_REGISTER); launch_map_register(a, c->stream);      // :836-846
     c->map_steps += 1;
     launch_map_report(a, (int)c->map_steps, c->stream); }

@@ -117,5 +117,7 @@ void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s);
 void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s);   // staging: 2 pools per sequence
 void launch_map_register(const MapArgs& a, hipStream_t s);
 void launch_map_report(const MapArgs& a, int step, hipStream_t s);
+int prepare_reference_order();                                                                  // reference_order_kernels.hip
+void launch_voxel_filter_reference_order(const VoxArgs& v, const MapArgs& a, bool stacks, hipStream_t s);
 
 }  // namespace aloam

@@ -1,0 +1,196 @@
+// a-loam_amd/csrc/reference_order_kernels.hip — pcl::VoxelGrid with the REFERENCE'S summation order (aloam_set_voxel_sum_order).
+//
+// The default path sums the members of a voxel in input order; pcl::VoxelGrid::applyFilter sums them in the order libstdc++'s unstable std::sort leaves
+// its (voxel index, point index) pairs in — up to 4 ulp apart in a centroid of three or more points, which the pipeline's discrete decisions amplify
+// into centimetres over hundreds of frames.  A context switched to the reference order runs these kernels instead of (mapping)
+// or after (registration: the values of the less-flat centroids are overwritten) the throughput filters: one workgroup per pcl::VoxelGrid::filter
+// call, the filter written out as PCL has it — bounding box, integer cell indices, index vector in input order, the sort REPLAYED step by step by
+// one lane (aloam_stdsort.hpp), members summed in the sorted order.  It is a validation mode: exact, an order of magnitude slower than the default.
+//   reference: src/scanRegistration.cpp:392-407 (less-flat points of one ring), src/laserMapping.cpp:542-550 (incoming stacks), :788-801 (valid cubes)
+#include "aloam_stdsort.hpp"
+#include "mapping_kernels.hpp"
+#include "registration_kernels.hpp"
+
+namespace aloam {
+
+namespace {
+
+using stdsort::Entry;
+constexpr int kLitThreads = 256;
+constexpr int kLitLdsEntries = 16384;                      // index vectors up to this size are sorted in LDS (128 KiB); longer ones in global scratch
+
+__device__ __forceinline__ float block_min(float v, float* s, int tid) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+  __syncthreads();
+  if ((tid & 63) == 0) s[tid >> 6] = v;
+  __syncthreads();
+  return fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
+}
+
+// The body of pcl::VoxelGrid<PointXYZI>::applyFilter for one call, by one workgroup of kLitThreads.
+//   point(i)   the i-th point of the filter's input cloud, i < n (input order)
+//   E          n entries of scratch (LDS or global), s_misc: >= 16 floats / ints of LDS, stack: stdsort::kStackInts ints of LDS
+//   out        receives the centroids in ascending cell order; returns their number (n and nothing written when PCL returns its input unfiltered:
+//              more than INT_MAX cells in the bounding box)
+template <class PointFn>
+__device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, Entry* E, float4* out, float* s_f, int* s_i, int* stack, bool* unfiltered) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float inv = 1.0f / leaf;                            // inverse_leaf_size_
+  float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+  for (int i = tid; i < n; i += kLitThreads) {              // getMinMax3D
+    const float4 p = point(i);
+    mn[0] = fminf(mn[0], p.x); mx[0] = fmaxf(mx[0], p.x);
+    mn[1] = fminf(mn[1], p.y); mx[1] = fmaxf(mx[1], p.y);
+    mn[2] = fminf(mn[2], p.z); mx[2] = fmaxf(mx[2], p.z);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { mn[k] = block_min(mn[k], s_f, tid); mx[k] = -block_min(-mx[k], s_f, tid); }
+  const long long dx = (long long)((mx[0] - mn[0]) * inv) + 1, dy = (long long)((mx[1] - mn[1]) * inv) + 1, dz = (long long)((mx[2] - mn[2]) * inv) + 1;
+  *unfiltered = dx * dy * dz > 2147483647ll;                // PCL warns and copies its input
+  if (*unfiltered) return n;
+  int minb[3], divb[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { minb[k] = (int)floorf(mn[k] * inv); divb[k] = (int)floorf(mx[k] * inv) - minb[k] + 1; }
+  const int mul1 = divb[0], mul2 = divb[0] * divb[1];
+  for (int i = tid; i < n; i += kLitThreads) {              // the index vector, in input order
+    const float4 p = point(i);
+    const int i0 = (int)(floorf(p.x * inv) - (float)minb[0]), i1 = (int)(floorf(p.y * inv) - (float)minb[1]), i2 = (int)(floorf(p.z * inv) - (float)minb[2]);
+    E[i] = Entry{(unsigned)(i0 + i1 * mul1 + i2 * mul2), (unsigned)i};
+  }
+  __syncthreads();
+  if (tid == 0) stdsort::sort(E, n, stack);                 // std::sort(index_vector.begin(), index_vector.end(), std::less<cloud_point_index_idx>())
+  __syncthreads();
+  // one output point per run of equal cell indices; the members are summed in the order the sort left them
+  int base = 0;
+  for (int p0 = 0; p0 < n; p0 += kLitThreads) {
+    const int p = p0 + tid;
+    const bool head = p < n && (p == 0 || E[p].idx != E[p - 1].idx);
+    const unsigned long long m = __ballot(head);
+    if (lane == 0) s_i[wave] = __popcll(m);
+    __syncthreads();
+    int rank = base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rank += s_i[w];
+    const int total = s_i[0] + s_i[1] + s_i[2] + s_i[3];
+    if (head) {
+      const unsigned cell = E[p].idx;
+      float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
+      int cnt = 0;
+      for (int q = p; q < n && E[q].idx == cell; ++q) {
+        const float4 pt = point((int)E[q].pt);
+        sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
+        ++cnt;
+      }
+      const float fc = (float)cnt;
+      out[rank] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
+    }
+    base += total;
+    __syncthreads();
+  }
+  return base;
+}
+
+}  // namespace
+
+// ---- mapping: every VoxSeg of the list (incoming stacks / valid cubes) -------------------------------------------------------------------------
+// scratch: 8 bytes per input point for index vectors that do not fit the LDS: the general voxel path's key buffer, addressed like the segment's
+// output (stacks: by sequence and class; cubes: the cube's own range of the pool-sized staging buffer, where `out` already points)
+__global__ __launch_bounds__(kLitThreads) void k_vox_reference_order(VoxArgs v, MapArgs a, int stacks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lit_smem[];
+  Entry* lds_E = reinterpret_cast<Entry*>(lit_smem);
+  int* stack = reinterpret_cast<int*>(lit_smem + sizeof(Entry) * kLitLdsEntries);
+  float* s_f = reinterpret_cast<float*>(stack + stdsort::kStackInts);
+  int* s_i = reinterpret_cast<int*>(s_f + 8);
+  __shared__ bool s_unfiltered;
+  const int tid = threadIdx.x;
+  for (int g = blockIdx.x; g < v.n_segs; g += gridDim.x) {
+    __syncthreads();
+    const VoxSeg sg = v.segs[g];
+    const int n = sg.n;
+    if (n <= 0) continue;
+    long long soff;
+    if (stacks) { const int b = g >> 1; soff = (long long)b * ((long long)a.cap + a.R * 120) + ((g & 1) ? a.R * 120 : 0); }
+    else soff = sg.out - v.tmp;
+    Entry* E = n <= kLitLdsEntries ? lds_E : reinterpret_cast<Entry*>(v.keys[0]) + soff;
+    const float4* in = sg.in;
+    bool unf;
+    const int n_vox = voxel_grid_reference_order([&](int i) { return in[i]; }, n, sg.leaf, E, sg.out, s_f, s_i, stack, &unf);
+    if (tid == 0) s_unfiltered = unf;
+    __syncthreads();
+    if (sg.final_out) {                                     // in-place cube filter: back over the cube once every member has been read
+      if (!s_unfiltered && sg.final_out != sg.out) for (int i = tid; i < n_vox; i += kLitThreads) sg.final_out[i] = sg.out[i];
+    } else if (s_unfiltered) {
+      for (int i = tid; i < n; i += kLitThreads) sg.out[i] = in[i];
+    }
+    if (tid == 0) { if (sg.final_count) *sg.final_count = n_vox; else if (sg.out_count) *sg.out_count = n_vox; }
+  }
+}
+
+// ---- registration: the less-flat points of one ring (src/scanRegistration.cpp:392-407) ------------------------------------------------------------
+// Runs after k_ring_features, which has selected the features, written cloudLabel and the less-flat centroids (input order) at their final place and
+// published every ring's count: this kernel recomputes the VALUES of a ring's centroids in the reference's order and writes them over the others
+// (the cells, their order and their number are the same by construction; a different count is reported as an internal error).
+__global__ __launch_bounds__(kLitThreads) void k_less_flat_reference_order(RegArgs a, float leaf) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lit_smem[];
+  const int b = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int start = a.ringstart[b * (a.R + 1) + r];
+  const int n = a.ringstart[b * (a.R + 1) + r + 1] - start;
+  const int L = n - 11;                                     // elements scanStartInd .. scanEndInd - 1 (:249-251,284-285)
+  if (L < 6) return;                                        // :279
+  constexpr int kMaxRing = 4107;
+  if (n > kMaxRing) return;                                 // k_ring_features has flagged the sweep (kErrRingCap)
+  Entry* E = reinterpret_cast<Entry*>(lit_smem);            // [kMaxRing]
+  unsigned short* member = reinterpret_cast<unsigned short*>(E + kMaxRing);   // [kMaxRing] element of the m-th member
+  int* stack = reinterpret_cast<int*>(member + kMaxRing + 1);
+  float* s_f = reinterpret_cast<float*>(stack + stdsort::kStackInts);
+  int* s_i = reinterpret_cast<int*>(s_f + 8);
+  const float4* cloud = a.cloud + (long long)b * a.cap + start + 5;
+  const int8_t* label = a.label + (long long)b * a.cap + start + 5;
+  // lessFlatScan: every element whose label is <= 0, in element order (:392-398)
+  int base = 0;
+  for (int e0 = 0; e0 < L; e0 += kLitThreads) {
+    const int e = e0 + tid;
+    const bool mem = e < L && label[e] <= 0;
+    const unsigned long long m = __ballot(mem);
+    if (lane == 0) s_i[wave] = __popcll(m);
+    __syncthreads();
+    int rank = base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rank += s_i[w];
+    if (mem) member[rank] = (unsigned short)e;
+    base += s_i[0] + s_i[1] + s_i[2] + s_i[3];
+    __syncthreads();
+  }
+  const int n_mem = base;
+  // this ring's place in the less-flat cloud: the counts the rings in front published in this launch
+  const unsigned long long* lb = a.lookback + (long long)b * 4 * a.R + 3 * a.R;
+  int off = 0;
+  for (int q = tid; q < r; q += kLitThreads) off += (int)(unsigned)lb[q];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) off += __shfl_xor(off, d, 64);
+  __syncthreads();
+  if (lane == 0) s_i[4 + wave] = off;
+  __syncthreads();
+  off = s_i[4] + s_i[5] + s_i[6] + s_i[7];
+  const int expect = (int)(unsigned)lb[r];
+  if (n_mem == 0) return;
+  bool unf;
+  float4* out = a.less_flat + (long long)b * a.cap + off;
+  const int n_vox = voxel_grid_reference_order([&](int i) { return cloud[member[i]]; }, n_mem, leaf, E, out, s_f, s_i, stack, &unf);
+  if (tid == 0 && (unf || n_vox != expect)) atomicOr(&a.meta[b].err, kErrInternal);
+}
+
+void launch_less_flat_reference_order(const RegArgs& a, float leaf, hipStream_t s) {
+  const size_t lds = sizeof(Entry) * 4107 + sizeof(unsigned short) * 4108 + sizeof(int) * (stdsort::kStackInts + 24);
+  hipLaunchKernelGGL(k_less_flat_reference_order, dim3(a.B, a.R), dim3(kLitThreads), lds, s, a, leaf);
+}
+
+static size_t vox_reference_lds_bytes() { return sizeof(Entry) * kLitLdsEntries + sizeof(int) * (stdsort::kStackInts + 24); }
+int prepare_reference_order() {
+  return hipFuncSetAttribute((const void*)k_vox_reference_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_reference_lds_bytes()) == hipSuccess ? 0 : -1;
+}
+void launch_voxel_filter_reference_order(const VoxArgs& v, const MapArgs& a, bool stacks, hipStream_t s) {
+  const int grid = v.n_segs < 8192 ? v.n_segs : 8192;
+  hipLaunchKernelGGL(k_vox_reference_order, dim3(grid), dim3(kLitThreads), vox_reference_lds_bytes(), s, v, a, stacks ? 1 : 0);
+}
+
+}  // namespace aloam

@@ -92,6 +92,13 @@ void aloam_destroy(aloam_ctx* ctx);
 const char* aloam_last_error(const aloam_ctx* ctx);                  /* replaces printf / ROS_BREAK diagnostics */
 void* aloam_stream(aloam_ctx* ctx);                                  /* the hipStream_t all work is queued on   */
 int aloam_synchronize(aloam_ctx* ctx);                               /* waits + surfaces device-side error flags */
+/* pcl::VoxelGrid (src/scanRegistration.cpp:402-405, src/laserMapping.cpp:543-549,793-799) sums the members of a voxel in the order an UNSTABLE
+ * std::sort leaves its index vector in.  ALOAM_SUM_INPUT_ORDER (default, the throughput path) sums them in input order: centroids of three or more
+ * points may differ from the reference's in their last bits (<= 4 ulp), nothing else does.  ALOAM_SUM_REFERENCE_ORDER replays libstdc++'s introsort
+ * step by step (one lane per filter call) and sums in the order it produces: the reference's bits, an order of magnitude slower - a validation
+ * mode for comparing long free-running sequences with the reference's own output.  Takes effect from the next call; not to be changed mid-sequence. */
+enum { ALOAM_SUM_INPUT_ORDER = 0, ALOAM_SUM_REFERENCE_ORDER = 1 };
+int aloam_set_voxel_sum_order(aloam_ctx* ctx, int order);
 
 /* ---- stage 1: body of laserCloudHandler (reference src/scanRegistration.cpp:127-411) ----------------------- */
 /* Host input: scans[b] points to n_in[b] records of stride_bytes.  Blocking w.r.t. the host buffers only.    */

@@ -452,3 +452,15 @@ def test_lm_scenarios_reach_every_solver_branch(O, sequence):
             assert st["termination"] == [5, 5] and st["lm_iterations"] == [0, 0] and np.allclose(pose["q_lc"], q) and np.allclose(pose["t_lc"], sc[5])
     assert {"termination0", "termination1", "termination2", "termination3", "termination5", "rejected_or_invalid"} <= set(cover), cover.keys()
     assert len(cover["rejected_or_invalid"]) >= 3
+
+
+def test_std_sort_order_restatement_matches_libstdcxx():
+    """a-loam_amd/csrc/aloam_stdsort.hpp (the sequence of swaps of libstdc++'s introsort, which decides the order pcl::VoxelGrid sums the members of a
+    voxel in; what the reference-order validation mode of the HIP path replays) compiled for the host against this toolchain's std::sort and
+    std::partial_sort: the same permutation on 30 000 arrays shaped like VoxelGrid's index vector (few distinct keys, runs, sorted / reversed stretches)."""
+    import subprocess
+    host = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
+    r = subprocess.run(["make", "-C", host, "build/test_stdsort_port"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(host, "build", "test_stdsort_port")], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("aloam_stdsort == std::sort"), r.stdout[-2000:]

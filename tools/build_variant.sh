@@ -5,5 +5,5 @@ set -e
 NAME=$1; shift
 cd "$(dirname "$0")/../a-loam_amd/csrc"
 mkdir -p ../lib/variants
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function "$@" -shared -o ../lib/variants/lib$NAME.so registration_kernels.hip odometry_kernels.hip mapping_kernels.hip aloam_capi.hip
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function "$@" -shared -o ../lib/variants/lib$NAME.so registration_kernels.hip odometry_kernels.hip mapping_kernels.hip reference_order_kernels.hip aloam_capi.hip
 echo a-loam_amd/lib/variants/lib$NAME.so
