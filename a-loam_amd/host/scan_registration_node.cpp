@@ -75,6 +75,9 @@ int main(int argc, char** argv) {
     ROS_ERROR("aloam_create: %s", g_ctx ? aloam_last_error(g_ctx) : "out of memory");
     return 1;
   }
+  int reference_sum_order = 0;                             // 1: pcl::VoxelGrid's own summation order (the reference's bits in the less-flat cloud; validation, slower)
+  nh.param<int>("reference_sum_order", reference_sum_order, 0);
+  if (reference_sum_order) aloam_set_voxel_sum_order(g_ctx, ALOAM_SUM_REFERENCE_ORDER);
   ros::Subscriber subLaserCloud = nh.subscribe<sensor_msgs::PointCloud2>("/velodyne_points", 100, laserCloudHandler);
   pubLaserCloud = nh.advertise<sensor_msgs::PointCloud2>("/velodyne_cloud_2", 100);
   pubCornerPointsSharp = nh.advertise<sensor_msgs::PointCloud2>("/laser_cloud_sharp", 100);

@@ -20,6 +20,7 @@ oracle in "canonical" order) sums the members of a voxel in input order where pc
 1.01212 on either side of 1.01213 - and then drift to 2 cm, a quarter of the reference's own one-ulp sensitivity.  So the tests assert: bit-exactness
 where it exists (literal order; the HIP path against the canonical oracle on IDENTICAL map state, every 25 frames at full map depth), the 1e-4 tolerance
 on the odometry chain throughout and on the refined poses until the first flipped decision, and the reference's own one-ulp envelope afterwards.
+With the reference's summation order switched on (aloam_set_voxel_sum_order) the device reproduces the reference's run itself: tests/test_reference_order.py.
 """
 import hashlib
 import json

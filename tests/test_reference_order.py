@@ -107,3 +107,32 @@ def test_three_hundred_free_running_frames_against_the_reference_codes_run(bindi
           f"{sha_equal} of {sha_total} class maps bit-identical by sha256 at the checkpoints; pool {gpu.map_pool_info()}")
     assert sha_equal >= sha_total - 4, (sha_equal, sha_total)
     gpu.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "reffullmap_*.npz"))))
+def test_full_chain_at_benchmark_size_is_the_reference_codes_bits(binding, sequence, path):
+    """64 x 2048 sweeps (index vectors of ~40 000 entries: beyond the LDS, sorted in global scratch) through registration -> odometry -> mapping in the
+    reference's order: refined poses to 1e-9 and every class map identical by sha256 to what the reference's three translation units produced."""
+    g = np.load(path)
+    scans, R, t, model = sequence(str(g["sensor"]), int(g["frames"]), seed=int(g["seed"]), **json.loads(str(g["kwargs"])))
+    for k, x in enumerate(scans):
+        assert _sha(x) == str(g[f"scan_sha{k}"])
+    gpu = binding.Aloam(n_scans=int(g["n_scans"]), min_range=float(g["min_range"]), max_points=int(g["max_points"]) + 256)
+    gpu.set_voxel_sum_order(True)
+    gpu.mapping_enable(float(g["line_res"]), float(g["plane_res"]), pool_points=131072)
+    for k, x in enumerate(scans):
+        gpu.scan_register(x)
+        gpu.odometry_step()
+        gpu.mapping_step()
+        gpu.synchronize()
+        pm = gpu.map_pose()
+        for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+            assert np.abs(pm[key] - g[f"{key}{k}"]).max() < 1e-9, (path, k, key)
+        reg = gpu.map_cloud(binding.MAP_REGISTERED)
+        assert len(reg) == int(g[f"registered_n{k}"])
+        for cls, name in ((0, "corner_map"), (1, "surf_map")):
+            cubes = gpu.map_cubes(cls)
+            ids = [int(i) for i in g[f"{name}_ids{k}"]]
+            assert sorted(cubes) == ids and [len(cubes[c]) for c in ids] == [int(c) for c in g[f"{name}_cnt{k}"]], (path, k, name)
+            assert _sha(np.concatenate([cubes[c] for c in ids])) == str(g[f"{name}_sha{k}"]), (path, k, name)
+    gpu.close()
