@@ -1007,7 +1007,7 @@ template <bool HALVES> __device__ __forceinline__ int seg_max_count(int n) {
 // DISTANCE_SQ_THRESHOLD); returns the improved packed 1-NN key.  `need`: this query takes part (HALVES: the other may be done already)
 template <int kRows, bool HALVES>
 __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, unsigned last_index, float cellc, float sx, float sy, float sz, unsigned long long nn, bool need,
-                                                            int lane, int last4, int* lds) {
+                                                            int lane, int last4, int* lds, int stat_cls = 0) {
   constexpr int W = HALVES ? 32 : 64;
   const int l = lane & (W - 1);
   const float invc = 1.0f / cellc;
@@ -1016,7 +1016,7 @@ __device__ __forceinline__ unsigned long long coarse_shells(const GridView& g, u
   const AxisGap ax = axis_gap_of(sx, ux, cellc), ay = axis_gap_of(sy, uy, cellc), az = axis_gap_of(sz, uz, cellc);
   const unsigned hm = (unsigned)(g.H - 1);
   unsigned long long t1 = nn;
-  ALOAM_STAT(0, 28, 1);
+  ALOAM_STAT(stat_cls, 28, 1); (void)stat_cls;       // (round 5's instrumented build counted both classes in the corner slot)
   for (int r = 1;; ++r) {
     const int ncell = r == 1 ? 27 : 24 * r * r + 2;
     const float limit = fminf(__uint_as_float((unsigned)(nn >> 32)), 25.0f);
@@ -1176,14 +1176,14 @@ __device__ __forceinline__ void associate_pair(const OdomArgs& a, int b, int qi0
     const bool need1 = qact && !(nn != ~0ull && __uint_as_float((unsigned)(nn >> 32)) <= bound2);
     const unsigned long long need = __ballot(need1);
     const bool n0 = need & 1ull, n1 = (need >> 32) & 1ull;
-    if (PAIRED_TAILS && n0 && n1) nn = coarse_shells<kRows1, true>(g, last_index, cell * kCell3CoarseFactor, sel.x, sel.y, sel.z, nn, need1, lane, last4, lds);
+    if (PAIRED_TAILS && n0 && n1) nn = coarse_shells<kRows1, true>(g, last_index, cell * kCell3CoarseFactor, sel.x, sel.y, sel.z, nn, need1, lane, last4, lds, PLANE ? 1 : 0);
     else if (n0 || n1) {
       const int q = n0 ? 0 : 1;
 #pragma unroll
       for (int qq = 0; qq < 2; ++qq) {                                       // (both, one after the other, in builds without the paired form)
         if (PAIRED_TAILS ? qq != q : !((need >> (32 * qq)) & 1ull)) continue;
         const unsigned long long r = coarse_shells<kRows1, false>(g, last_index, cell * kCell3CoarseFactor, read_f32(sel.x, 32 * qq), read_f32(sel.y, 32 * qq), read_f32(sel.z, 32 * qq),
-                                                                    read_u64(nn, 32 * qq), true, lane, 0, lds);
+                                                                    read_u64(nn, 32 * qq), true, lane, 0, lds, PLANE ? 1 : 0);
         if (hsel == qq) nn = r;
       }
     }

@@ -32,17 +32,22 @@ def main(tag, prefix):
     for name in ("two_rank_shared_gpu.json", "eight_rank_shared_gpu.json", "launcher_rccl_one_rank.json"):   # written by the -m gpu tests of the same call
         if os.path.exists(os.path.join(ROOT, "gpurun_out", name)):
             shutil.copyfile(os.path.join(ROOT, "gpurun_out", name), os.path.join(dst, f"{prefix}_{name}"))
-    for cfg in ("headline", "mapping", "rows128"):
-        cp(f"kernel_stats_{cfg}.md", f"{prefix}_kernel_stats_{cfg}_b{batch}.md")
+    map_batch = next((w["sequences_per_gpu"] for k, w in json.loads(line).get("workloads", {}).items() if "steady-state" in k), 256)   # --mapping = the travelling workload
+    for cfg in ("headline", "mapping", "rows128", "travel"):
+        if os.path.exists(os.path.join(src, f"kernel_stats_{cfg}.md")):
+            cp(f"kernel_stats_{cfg}.md", f"{prefix}_kernel_stats_{cfg}_b{map_batch if cfg == 'mapping' else batch}.md")
+    for extra in ("pmc_mapping_sq1.md", "pmc_mapping_tcp.md"):
+        if os.path.exists(os.path.join(src, extra)):
+            cp(extra, f"{prefix}_{extra[:-3]}_b{map_batch}.md")
     for c in ("fetch", "write", "sq1", "sq2"):
         cp(f"pmc_headline/pmc_{c}.md", f"{prefix}_pmc_{c}_headline_b{batch}.md")
     traffic = {"headline": json.load(open(os.path.join(src, "pmc_headline", "pmc_traffic.json")))}
     traffic["headline"]["source"] += f"; profiles/{prefix}_pmc_fetch_headline_b{batch}.md, {prefix}_pmc_write_headline_b{batch}.md"
     for cfg, args, sensor in (("mapping", "--mapping", "HDL-64"), ("rows128", "--sensor ROWS128", "ROWS128")):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            cp(f"pmc_{cfg}_{c}.md", f"{prefix}_pmc_{c.split('_')[0].lower()}_{cfg}_b{batch}.md")
+            cp(f"pmc_{cfg}_{c}.md", f"{prefix}_pmc_{c.split('_')[0].lower()}_{cfg}_b{map_batch if cfg == 'mapping' else batch}.md")
         fj, wj = (json.load(open(os.path.join(src, f"pmc_{cfg}_{c}.json"))) for c in ("FETCH_SIZE", "WRITE_SIZE"))
-        traffic[cfg] = {"batch": batch, "mapping": cfg == "mapping", "sensor": sensor, "lib_sha256": here,
+        traffic[cfg] = {"batch": map_batch if cfg == "mapping" else batch, "mapping": cfg == "mapping", "sensor": sensor, "lib_sha256": here,
                         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 {args} "
                                   f"(tools/gpu_evidence.sh); profiles/{prefix}_pmc_fetch_{cfg}_b{batch}.md, {prefix}_pmc_write_{cfg}_b{batch}.md",
                         "fetch_kib": {k: v["FETCH_SIZE"] for k, v in fj.items() if "FETCH_SIZE" in v}, "write_kib": {k: v["WRITE_SIZE"] for k, v in wj.items() if "WRITE_SIZE" in v},
