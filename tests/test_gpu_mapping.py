@@ -315,3 +315,47 @@ def test_voxel_filter_segments_the_lds_kernel_hands_to_the_general_path(O, bindi
         for cls in (0, 1):
             _compare_maps(gpu.map_cubes(cls), orc.map_cubes(cls), (case, k, cls))
     gpu.close()
+
+
+def test_pools_grow_under_asynchronous_steps_without_dropping_a_point(binding, syn):
+    """The throughput use: sweeps resident on the device, aloam_process_device + aloam_mapping_step queued for 120 frames WITHOUT a single synchronisation
+    in between, four travelling sequences, pools that start far too small (16 384 points).  The host has to size the pools ahead of the device from
+    the occupancy report of steps that finished a few steps ago (map_ensure_capacity): no ALOAM_E_CAPACITY at the end, the pools have grown, and the
+    map, the window and the poses are those of a run that synchronises after every step with pools that never need to grow - bit for bit."""
+    import torch
+    B, T, cols = 4, 120, 512
+    dev = torch.device("cuda", 0)
+    model = syn.sensor_model("HDL-64", columns=cols, device=dev)
+    NP = model.dirs.shape[0]
+    data = torch.zeros((B, T, NP, 4), dtype=torch.float32, device=dev)
+    counts = np.zeros((B, T), np.int32)
+    for b in range(B):
+        world = syn.make_street_world(70 + b).to(dev)
+        R, t = syn.trajectory_travel(T, step=1.6, seed=70 + b)
+        gen = torch.Generator(device=dev).manual_seed(500 + b)
+        for k in range(T):
+            s = syn.render_scan(world, model, R[k], t[k], 0.02, gen, max_range=syn.STREET_MAX_RANGE, cull=True)
+            counts[b, k] = s.shape[0]
+            data[b, k, : s.shape[0]] = s
+    torch.cuda.synchronize()
+    results = []
+    for asynchronous in (True, False):
+        gpu = binding.Aloam(n_scans=64, min_range=5.0, batch=B, max_points=NP)
+        gpu.mapping_enable(0.4, 0.8, pool_points=16384 if asynchronous else 524288)
+        for k in range(T):
+            gpu.process_device(data.data_ptr() + k * NP * 16, T * NP * 16, counts[:, k])
+            gpu.mapping_step()
+            if not asynchronous:
+                gpu.synchronize()
+        gpu.synchronize()                                      # raises ALOAM_E_CAPACITY if any step dropped points
+        pool = gpu.map_pool_info()
+        results.append(([gpu.map_pose(b) for b in range(B)], [[gpu.map_cubes(cls, b) for cls in (0, 1)] for b in range(B)], [gpu.map_info(b) for b in range(B)], pool))
+        gpu.close()
+    (pa, ca, ia, pool_a), (ps, cs, is_, pool_s) = results
+    assert pool_a["growths"] >= 2 and pool_a["pool_points"] >= pool_a["live_max"] > 16384 and pool_s["growths"] == 0, (pool_a, pool_s)
+    for b in range(B):
+        for key in ("q_w", "t_w", "q_wmap_wodom", "t_wmap_wodom"):
+            assert np.array_equal(pa[b][key], ps[b][key]), (b, key)
+        assert {k: v for k, v in ia[b].items() if k != "compactions"} == {k: v for k, v in is_[b].items() if k != "compactions"}, (b, ia[b], is_[b])
+        for cls in (0, 1):
+            _compare_maps(ca[b][cls], cs[b][cls], (b, cls))
