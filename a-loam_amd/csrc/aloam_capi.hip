@@ -78,6 +78,7 @@ struct aloam_ctx {
   int map_growths = 0;
   long long map_steps = 0;           // mapping steps queued so far
   int nin_max = 0;                   // largest scan handed to the last registration call (bounds what one step can add to a map)
+  int inject_max = 0;                // largest cloud injected through aloam_set_last since the last mapping step (the same bound for a mapping-only context)
   volatile int* h_map_report = nullptr;   // pinned: {step, live corner, live surf, stack corner, stack surf} of the last finished step
   int* d_map_report_host = nullptr;       // the same memory as the device sees it
   int* d_map_report = nullptr; int* d_map_live = nullptr;
@@ -692,6 +693,7 @@ int aloam_set_last(aloam_ctx* c, int seq, const float* corner_last, int n_corner
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if (n_corner < 0 || n_corner > c->R * 120 || n_surf < 0 || n_surf > c->cap) { c->err = "last cloud too large"; return ALOAM_E_CAPACITY; }
+  c->inject_max = std::max(c->inject_max, std::max(n_corner, n_surf));
   if (!c->d_less_sharp[1 - c->cur]) { c->err = "this context has no buffers for the last clouds (created for the registration stage only)"; return ALOAM_E_STATE; }
   const size_t b = seq;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1089,6 +1091,7 @@ int aloam_mapping_step(aloam_ctx* c) {
   // at most four steps queued ahead of the device: the occupancy report the pools are sized from is never older than that
   hipEvent_t done = c->map_step_done[c->map_steps & 3];
   if (c->map_steps >= 4) HIP_TRY(c, hipEventSynchronize(done));
+  if (c->inject_max > 0) { c->nin_max = c->inject_max; c->inject_max = 0; }   // this step's clouds came through aloam_set_last
   int rc = map_ensure_capacity(c);
   if (rc) return rc;
   const MapArgs a = map_args(c);
