@@ -88,7 +88,7 @@ def parse_args():
     ap.add_argument("--sensor", default="HDL-64", help="headline workload sensor (HDL-64 = BASELINE configs[1]; ROWS128 = configs[3])")
     ap.add_argument("--mapping", action="store_true", help="headline workload = BASELINE configs[2]: scan-to-map refinement after every sweep")
     ap.add_argument("--map-pool", type=int, default=262144, help="device map capacity per sequence and class the contexts START with (points; the pools double as the maps grow)")
-    ap.add_argument("--map-batch", type=int, default=256, help="sequences per GPU of the configs[2] workload (travelling sensor, --map-frames distinct sweeps each)")
+    ap.add_argument("--map-batch", type=int, default=512, help="sequences per GPU of the configs[2] workload (travelling sensor, --map-frames distinct sweeps each)")
     ap.add_argument("--map-frames", type=int, default=100)
     ap.add_argument("--map-warmup", type=int, default=80, help="untimed steps of the configs[2] workload: 125 m of travel, after which the submap is stationary")
     ap.add_argument("--contexts", type=int, default=1, help="split the batch over this many contexts (= HIP streams) on the same GPU")
