@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--from-kitti", help="dataset_folder of kitti_helper.launch: write its lidar sweeps as a bag instead of running")
     ap.add_argument("--seq", default="00")
     ap.add_argument("--write-bag")
+    ap.add_argument("--reference-order", action="store_true", help="sum voxel members in pcl::VoxelGrid's own order (the reference's bits; ~15x slower): for runs that are compared pose by pose with A-LOAM's")
     ap.add_argument("--selftest", action="store_true")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -82,6 +83,8 @@ def main():
         write_bag(args.bag, [s.numpy() for s in scans], [0.1 * k for k in range(len(scans))], compression="bz2")
     binding = importlib.import_module("a-loam_amd.binding")
     gpu = binding.Aloam(n_scans=args.scan_line, min_range=args.minimum_range, max_points=400000)
+    if args.reference_order:
+        gpu.set_voxel_sum_order(True)
     if args.mapping:
         gpu.mapping_enable(args.line_res, args.plane_res, pool_points=1 << 17)   # grows with the map
     odo, mapped = [], []

@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--mapping", action="store_true")
     ap.add_argument("--max-frames", type=int, default=0)
     ap.add_argument("--selftest", action="store_true")
+    ap.add_argument("--reference-order", action="store_true", help="sum voxel members in pcl::VoxelGrid's own order (the reference's bits; ~15x slower): for runs that are compared pose by pose with A-LOAM's")
     ap.add_argument("--distortion", action="store_true", help="per-point interpolation ratio (the reference's DISTORTION 1; real KITTI sweeps are already de-skewed, so the reference ships 0)")
     args = ap.parse_args()
     if args.selftest:
@@ -82,6 +83,8 @@ def main():
     gt = read_gt(gt_path) if os.path.exists(gt_path) else None
     # launch/aloam_velodyne_HDL_64.launch: scan_line 64, minimum_range 5, mapping resolutions 0.4 / 0.8
     gpu = binding.Aloam(n_scans=64, min_range=5.0, max_points=140000, distortion=args.distortion)
+    if args.reference_order:
+        gpu.set_voxel_sum_order(True)
     if args.mapping:
         gpu.mapping_enable(0.4, 0.8, pool_points=1 << 17)          # where the map starts: the pools double as it grows (src/laserMapping.cpp:737-783 push_back)
     os.makedirs(args.out, exist_ok=True)
