@@ -139,5 +139,83 @@ ALOAM_SS_HD void sort(Entry* a, int n, int* stack) {
   } else insertion_sort(a, 0, n);
 }
 
+// ---- the same partition as DATA-PARALLEL steps (what a workgroup does for a large range; reference_order_kernels.hip) ----------------------------------
+// __unguarded_partition alternates two scans: f runs up to the next element >= pivot, l runs down to the next element <= pivot, they swap, until
+// they meet.  Until they meet both scans only ever look at elements no swap has touched, so the i-th stop of f is the i-th position (ascending,
+// from first + 1) whose ORIGINAL key is >= pivot, F_i, and the i-th stop of l the i-th position (descending, from last - 1; `first` itself, the
+// pivot, is the last stop l can reach) whose original key is <= pivot, L_i.  Pairs (F_i, L_i) are swapped while F_i < L_i - m of them, and since F
+// ascends while L descends all F_i of swapped pairs lie left of all their L_i: the swaps are independent.  After the m-th swap f runs on to F_(m+1)
+// unless it meets the element it has just put at L_m first (>= pivot by construction): cut = min(F_(m+1), L_m).  Two prefix counts, a rank match
+// and a scatter - partition_by_lists() below is that formulation run sequentially, so that the host test can hold it against partition_pivot()
+// (and both against std::sort); the device runs the same steps with wave ballots and block scans.
+//   fpos / lpos: scratch for the two position lists (last - first entries each are enough).
+ALOAM_SS_HD void median_to_first(Entry* a, int first, int last) {
+  const int mid = first + (last - first) / 2;
+  const int x = first + 1, y = mid, z = last - 1;
+  if (less(a[x], a[y])) {
+    if (less(a[y], a[z])) swap_entries(a, first, y);
+    else if (less(a[x], a[z])) swap_entries(a, first, z);
+    else swap_entries(a, first, x);
+  } else if (less(a[x], a[z])) swap_entries(a, first, x);
+  else if (less(a[y], a[z])) swap_entries(a, first, z);
+  else swap_entries(a, first, y);
+}
+ALOAM_SS_HD int cut_from_lists(const int* fpos, int nf, const int* lpos, int nl, int m) {
+  const int fnext = m < nf ? fpos[m] : 0x7fffffff;                 // F_(m+1) (0-based lists)
+  const int lm = m > 0 ? lpos[m - 1] : 0x7fffffff;                 // L_m
+  return fnext < lm ? fnext : lm;
+}
+ALOAM_SS_HD int partition_by_lists(Entry* a, int first, int last, int* fpos, int* lpos) {
+  median_to_first(a, first, last);
+  const unsigned pv = a[first].idx;
+  int nf = 0, nl = 0;
+  for (int p = first + 1; p < last; ++p) if (a[p].idx >= pv) fpos[nf++] = p;
+  for (int p = last - 1; p > first; --p) if (a[p].idx <= pv) lpos[nl++] = p;
+  lpos[nl++] = first;                                               // the pivot: the stop l cannot pass
+  int m = 0;
+  while (m < nf && m < nl && fpos[m] < lpos[m]) ++m;
+  for (int i = 0; i < m; ++i) swap_entries(a, fpos[i], lpos[i]);
+  return cut_from_lists(fpos, nf, lpos, nl, m);
+}
+
+// std::sort in the shape the device gives it: ranges of `big` elements and more are partitioned by lists (a workgroup), smaller ones become CHUNKS
+// that one lane finishes on its own - introsort loop with the depth limit the range has inherited, then the insertion sort, which never moves an
+// element across a cut (everything left of a cut is <= everything right of it), so finishing chunk by chunk IS the final insertion sort.
+//   work: 3 ints per pending range (first, last, depth): at most (last - first) / big * 2 + 72 of them; chunk_fn(first, last, depth) is called once
+//   per chunk, in any order.
+template <class ChunkFn>
+ALOAM_SS_HD void sort_by_chunks(Entry* a, int n, int big, int* work, int* fpos, int* lpos, ChunkFn&& chunk_fn) {
+  if (n <= 0) return;
+  int lg = 0;
+  while ((n >> (lg + 1)) != 0) ++lg;
+  int sp = 0;
+  work[0] = 0; work[1] = n; work[2] = 2 * lg; sp = 1;
+  while (sp > 0) {
+    --sp;
+    const int first = work[3 * sp], last = work[3 * sp + 1], depth = work[3 * sp + 2];
+    if (last - first < big || last - first <= kThreshold || depth == 0) { chunk_fn(first, last, depth); continue; }
+    const int cut = partition_by_lists(a, first, last, fpos, lpos);
+    work[3 * sp] = first; work[3 * sp + 1] = cut; work[3 * sp + 2] = depth - 1; ++sp;
+    work[3 * sp] = cut; work[3 * sp + 1] = last; work[3 * sp + 2] = depth - 1; ++sp;
+  }
+}
+// one chunk, by one lane: __introsort_loop(first, last, depth) and the insertion sort of the stretch
+ALOAM_SS_HD void finish_chunk(Entry* a, int first, int last, int depth, int* stack) {
+  int sp = 0;
+  stack[0] = first; stack[1] = last; stack[2] = depth; sp = 1;
+  while (sp > 0) {
+    --sp;
+    int f = stack[3 * sp], l = stack[3 * sp + 1], d = stack[3 * sp + 2];
+    while (l - f > kThreshold) {
+      if (d == 0) { heap_sort(a + f, l - f); break; }
+      --d;
+      const int cut = partition_pivot(a, f, l);
+      stack[3 * sp] = cut; stack[3 * sp + 1] = l; stack[3 * sp + 2] = d; ++sp;
+      l = cut;
+    }
+  }
+  insertion_sort(a, first, last);
+}
+
 }  // namespace stdsort
 }  // namespace aloam

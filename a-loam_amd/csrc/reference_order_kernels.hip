@@ -28,13 +28,104 @@ __device__ __forceinline__ float block_min(float v, float* s, int tid) {
   return fminf(fminf(s[0], s[1]), fminf(s[2], s[3]));
 }
 
+// std::sort of E[0, n) by the whole workgroup, swap for swap what one lane running stdsort::sort() produces (aloam_stdsort.hpp, "the same partition as
+// data-parallel steps"): ranges of kBigRange elements and more are partitioned cooperatively - the two stop lists by ballot ranks, tile after tile, the
+// rank match, the independent swaps -, smaller ranges become chunks that single lanes finish (introsort loop + insertion sort of the stretch).
+//   fpos: n - 1 ints, lpos: n ints (global or LDS); s_work: 3 * kWorkMax ints, s_chunk: 3 * kChunkMax ints, s_i: >= 16 ints of LDS
+constexpr int kBigRange = 128, kWorkMax = 256, kChunkMax = 2048, kSeqSort = 96;
+__device__ void sort_reference_order(Entry* E, int n, int* fpos, int* lpos, int* s_work, int* s_chunk, int* s_i) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int stack[3 * 48];                                                         // private: pending ranges of one lane's introsort loop (depth <= 2 lg n <= 46 here)
+  if (n <= kSeqSort) {                                                       // short index vectors: one lane, start to finish
+    if (tid == 0) stdsort::sort(E, n, stack);
+    __syncthreads();
+    return;
+  }
+  if (tid == 0) {
+    int lg = 0;
+    while ((n >> (lg + 1)) != 0) ++lg;
+    s_work[0] = 0; s_work[1] = n; s_work[2] = 2 * lg;
+    s_i[8] = 1; s_i[9] = 0;                                                  // pending ranges, chunks
+  }
+  __syncthreads();
+  while (s_i[8] > 0) {
+    const int sp = s_i[8] - 1;
+    const int first = s_work[3 * sp], last = s_work[3 * sp + 1], depth = s_work[3 * sp + 2];
+    __syncthreads();
+    if (last - first < kBigRange || depth == 0 || s_i[8] + 2 > kWorkMax) {   // a chunk (also: out of depth -> the lane heap-sorts it; work list full)
+      if (tid == 0) {
+        const int c = s_i[9];
+        if (c < kChunkMax) { s_chunk[3 * c] = first; s_chunk[3 * c + 1] = last; s_chunk[3 * c + 2] = depth; s_i[9] = c + 1; }
+        else stdsort::finish_chunk(E, first, last, depth, stack);            // (chunk list full: finished on the spot)
+        s_i[8] = sp;
+      }
+      __syncthreads();
+      continue;
+    }
+    if (tid == 0) stdsort::median_to_first(E, first, last);
+    __syncthreads();
+    const unsigned pv = E[first].idx;
+    // the stops of f: positions first + 1 .. last - 1, ascending, key >= pivot
+    int nf = 0;
+    for (int p0 = first + 1; p0 < last; p0 += kLitThreads) {
+      const int p = p0 + tid;
+      const bool in = p < last && E[p].idx >= pv;
+      const unsigned long long m = __ballot(in);
+      if (lane == 0) s_i[wave] = __popcll(m);
+      __syncthreads();
+      int r = nf + __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) r += s_i[w];
+      if (in) fpos[r] = p;
+      nf += s_i[0] + s_i[1] + s_i[2] + s_i[3];
+      __syncthreads();
+    }
+    // the stops of l: positions last - 1 .. first + 1, descending, key <= pivot; then the pivot itself
+    int nl = 0;
+    for (int p0 = last - 1; p0 > first; p0 -= kLitThreads) {
+      const int p = p0 - tid;
+      const bool in = p > first && E[p].idx <= pv;
+      const unsigned long long m = __ballot(in);
+      if (lane == 0) s_i[wave] = __popcll(m);
+      __syncthreads();
+      int r = nl + __popcll(m & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wave; ++w) r += s_i[w];
+      if (in) lpos[r] = p;
+      nl += s_i[0] + s_i[1] + s_i[2] + s_i[3];
+      __syncthreads();
+    }
+    if (tid == 0) { lpos[nl] = first; s_i[10] = 0; }
+    nl += 1;
+    __syncthreads();
+    // pairs that swap: F_i < L_i (true for a prefix of the pairs: F ascends, L descends)
+    const int np = nf < nl ? nf : nl;
+    int mine = 0;
+    for (int i = tid; i < np; i += kLitThreads) mine += fpos[i] < lpos[i] ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane == 0) atomicAdd(&s_i[10], mine);
+    __syncthreads();
+    const int m = s_i[10];
+    for (int i = tid; i < m; i += kLitThreads) { const int x = fpos[i], y = lpos[i]; const Entry t = E[x]; E[x] = E[y]; E[y] = t; }
+    if (tid == 0) {
+      const int cut = stdsort::cut_from_lists(fpos, nf, lpos, nl, m);
+      s_work[3 * sp] = first; s_work[3 * sp + 1] = cut; s_work[3 * sp + 2] = depth - 1;
+      s_work[3 * sp + 3] = cut; s_work[3 * sp + 4] = last; s_work[3 * sp + 5] = depth - 1;
+      s_i[8] = sp + 2;
+    }
+    __syncthreads();
+  }
+  const int nchunk = s_i[9];
+  for (int c = tid; c < nchunk; c += kLitThreads) stdsort::finish_chunk(E, s_chunk[3 * c], s_chunk[3 * c + 1], s_chunk[3 * c + 2], stack);
+  __syncthreads();
+}
+
 // The body of pcl::VoxelGrid<PointXYZI>::applyFilter for one call, by one workgroup of kLitThreads.
 //   point(i)   the i-th point of the filter's input cloud, i < n (input order)
-//   E          n entries of scratch (LDS or global), s_misc: >= 16 floats / ints of LDS, stack: stdsort::kStackInts ints of LDS
+//   E          n entries of scratch (LDS or global); fpos / lpos: n + 1 ints each; s_f: 8 floats, s_i: 16 ints, s_work / s_chunk: the lists of sort_reference_order (LDS)
 //   out        receives the centroids in ascending cell order; returns their number (n and nothing written when PCL returns its input unfiltered:
 //              more than INT_MAX cells in the bounding box)
 template <class PointFn>
-__device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, Entry* E, float4* out, float* s_f, int* s_i, int* stack, bool* unfiltered) {
+__device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, Entry* E, float4* out, float* s_f, int* s_i, int* s_work, int* s_chunk, int* fpos, int* lpos, bool* unfiltered) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float inv = 1.0f / leaf;                            // inverse_leaf_size_
   float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
@@ -59,8 +150,7 @@ __device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, En
     E[i] = Entry{(unsigned)(i0 + i1 * mul1 + i2 * mul2), (unsigned)i};
   }
   __syncthreads();
-  if (tid == 0) stdsort::sort(E, n, stack);                 // std::sort(index_vector.begin(), index_vector.end(), std::less<cloud_point_index_idx>())
-  __syncthreads();
+  sort_reference_order(E, n, fpos, lpos, s_work, s_chunk, s_i);   // std::sort(index_vector.begin(), index_vector.end(), std::less<cloud_point_index_idx>())
   // one output point per run of equal cell indices; the members are summed in the order the sort left them
   int base = 0;
   for (int p0 = 0; p0 < n; p0 += kLitThreads) {
@@ -98,8 +188,9 @@ __device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, En
 __global__ __launch_bounds__(kLitThreads) void k_vox_reference_order(VoxArgs v, MapArgs a, int stacks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lit_smem[];
   Entry* lds_E = reinterpret_cast<Entry*>(lit_smem);
-  int* stack = reinterpret_cast<int*>(lit_smem + sizeof(Entry) * kLitLdsEntries);
-  float* s_f = reinterpret_cast<float*>(stack + stdsort::kStackInts);
+  int* s_work = reinterpret_cast<int*>(lit_smem + sizeof(Entry) * kLitLdsEntries);
+  int* s_chunk = s_work + 3 * kWorkMax;
+  float* s_f = reinterpret_cast<float*>(s_chunk + 3 * kChunkMax);
   int* s_i = reinterpret_cast<int*>(s_f + 8);
   __shared__ bool s_unfiltered;
   const int tid = threadIdx.x;
@@ -112,9 +203,11 @@ __global__ __launch_bounds__(kLitThreads) void k_vox_reference_order(VoxArgs v, 
     if (stacks) { const int b = g >> 1; soff = (long long)b * ((long long)a.cap + a.R * 120) + ((g & 1) ? a.R * 120 : 0); }
     else soff = sg.out - v.tmp;
     Entry* E = n <= kLitLdsEntries ? lds_E : reinterpret_cast<Entry*>(v.keys[0]) + soff;
+    int* fpos = reinterpret_cast<int*>(v.keys[1] + soff);                    // the two stop lists of a cooperative partition: 2 x 4 bytes per point of the second key buffer
+    int* lpos = fpos + n - 1;                                                // (at most S - 1 stops of f and S stops of l in a range of S <= n elements: 2 n - 1 ints)
     const float4* in = sg.in;
     bool unf;
-    const int n_vox = voxel_grid_reference_order([&](int i) { return in[i]; }, n, sg.leaf, E, sg.out, s_f, s_i, stack, &unf);
+    const int n_vox = voxel_grid_reference_order([&](int i) { return in[i]; }, n, sg.leaf, E, sg.out, s_f, s_i, s_work, s_chunk, fpos, lpos, &unf);
     if (tid == 0) s_unfiltered = unf;
     __syncthreads();
     if (sg.final_out) {                                     // in-place cube filter: back over the cube once every member has been read
@@ -141,8 +234,11 @@ __global__ __launch_bounds__(kLitThreads) void k_less_flat_reference_order(RegAr
   if (n > kMaxRing) return;                                 // k_ring_features has flagged the sweep (kErrRingCap)
   Entry* E = reinterpret_cast<Entry*>(lit_smem);            // [kMaxRing]
   unsigned short* member = reinterpret_cast<unsigned short*>(E + kMaxRing);   // [kMaxRing] element of the m-th member
-  int* stack = reinterpret_cast<int*>(member + kMaxRing + 1);
-  float* s_f = reinterpret_cast<float*>(stack + stdsort::kStackInts);
+  int* fpos = reinterpret_cast<int*>(member + kMaxRing + 1);                  // [kMaxRing + 1] x 2
+  int* lpos = fpos + kMaxRing + 1;
+  int* s_work = lpos + kMaxRing + 1;
+  int* s_chunk = s_work + 3 * kWorkMax;
+  float* s_f = reinterpret_cast<float*>(s_chunk + 3 * kChunkMax);
   int* s_i = reinterpret_cast<int*>(s_f + 8);
   const float4* cloud = a.cloud + (long long)b * a.cap + start + 5;
   const int8_t* label = a.label + (long long)b * a.cap + start + 5;
@@ -175,16 +271,16 @@ __global__ __launch_bounds__(kLitThreads) void k_less_flat_reference_order(RegAr
   if (n_mem == 0) return;
   bool unf;
   float4* out = a.less_flat + (long long)b * a.cap + off;
-  const int n_vox = voxel_grid_reference_order([&](int i) { return cloud[member[i]]; }, n_mem, leaf, E, out, s_f, s_i, stack, &unf);
+  const int n_vox = voxel_grid_reference_order([&](int i) { return cloud[member[i]]; }, n_mem, leaf, E, out, s_f, s_i, s_work, s_chunk, fpos, lpos, &unf);
   if (tid == 0 && (unf || n_vox != expect)) atomicOr(&a.meta[b].err, kErrInternal);
 }
 
 void launch_less_flat_reference_order(const RegArgs& a, float leaf, hipStream_t s) {
-  const size_t lds = sizeof(Entry) * 4107 + sizeof(unsigned short) * 4108 + sizeof(int) * (stdsort::kStackInts + 24);
+  const size_t lds = sizeof(Entry) * 4107 + sizeof(unsigned short) * 4108 + sizeof(int) * (2 * 4108 + 3 * kWorkMax + 3 * kChunkMax + 24);
   hipLaunchKernelGGL(k_less_flat_reference_order, dim3(a.B, a.R), dim3(kLitThreads), lds, s, a, leaf);
 }
 
-static size_t vox_reference_lds_bytes() { return sizeof(Entry) * kLitLdsEntries + sizeof(int) * (stdsort::kStackInts + 24); }
+static size_t vox_reference_lds_bytes() { return sizeof(Entry) * kLitLdsEntries + sizeof(int) * (3 * kWorkMax + 3 * kChunkMax + 24); }
 int prepare_reference_order() {
   return hipFuncSetAttribute((const void*)k_vox_reference_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_reference_lds_bytes()) == hipSuccess ? 0 : -1;
 }

@@ -98,6 +98,7 @@ def parse_args():
     ap.add_argument("--host-input", action="store_true", help="(kept for compatibility: the host-fed rate is part of the default line)")
     ap.add_argument("--latency-sweeps", type=int, default=120)
     ap.add_argument("--travel", action="store_true", help="odometry-only workload on the travelling drive (the configs[2] input: 1.6 m per sweep down a street, 120 m range) instead of laps of the 30 m circle; --frames distinct sweeps per sequence")
+    ap.add_argument("--reference-order", action="store_true", help="run the workload of this call in the reference's voxel summation order (aloam_set_voxel_sum_order: the validation mode, std::sort replayed on the device) and say so in config")
     ap.add_argument("--rough", action="store_true", help="KITTI-shaped irregular sweeps (random no-returns, ragged rings, noisy sectors, repeated returns) instead of the clean synthetic ones")
     return ap.parse_args()
 
@@ -672,6 +673,9 @@ def main():
     NC = max(1, args.contexts)
     assert B % NC == 0, "--batch must be a multiple of --contexts"
     ctxs = [wl.ctx(binding, B // NC, local_rank) for _ in range(NC)]
+    if args.reference_order:
+        for c in ctxs:
+            c.set_voxel_sum_order(True)
     if args.mapping:
         for c in ctxs:
             c.mapping_enable(0.4, 0.8, args.map_pool)      # launch/aloam_velodyne_HDL_64.launch: mapping_line / plane_resolution
@@ -693,7 +697,7 @@ def main():
     out = {"metric": "HDL-64 scans/sec (whole node)", "value": round(value, 2), "unit": "scans/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 features / f64 solve", "data": "synthetic",
-           "config": {"workload": wl.describe(args.mapping), "sequences_per_gpu": B, "contexts_per_gpu": NC, "stored_frames": T,
+           "config": {"workload": wl.describe(args.mapping), "sequences_per_gpu": B, "contexts_per_gpu": NC, "stored_frames": T, "voxel_sum_order": "reference (std::sort replayed, validation mode)" if args.reference_order else "input order (throughput path)",
                       "points_per_sweep": wl.NP, "parallelism": f"{world} x independent sequence shards, no collectives"},
            "roofline": roofline_of(prof, args.steps, B, args.sensor, args.mapping), "input_generation_s": round(wl.gen_s, 2),
            "timed_region_s": round(elapsed, 3), "library_sha256": lib_sha256(),

@@ -32,6 +32,17 @@ int main() {
       aloam::stdsort::heap_sort(d.data(), (int)d.size());
       if (!same(c, d)) { std::printf("MISMATCH heap sort n=%zu (%s)\n", v.size(), what); std::exit(1); }
     }
+    {   // the data-parallel formulation: large ranges partitioned by lists, chunks finished one by one (in reverse order: any order must do)
+      std::vector<Entry> e = v;
+      std::vector<int> work(3 * (v.size() / 8 + 80)), fpos(v.size() + 2), lpos(v.size() + 2);
+      std::vector<int> chunks;
+      for (int big : {24, 300}) {
+        e = v; chunks.clear();
+        aloam::stdsort::sort_by_chunks(e.data(), (int)e.size(), big, work.data(), fpos.data(), lpos.data(), [&](int f, int l, int d) { chunks.push_back(f); chunks.push_back(l); chunks.push_back(d); });
+        for (size_t c = 0; c < chunks.size(); c += 3) aloam::stdsort::finish_chunk(e.data(), chunks[c], chunks[c + 1], chunks[c + 2], stack);
+        if (!same(a, e)) { std::printf("MISMATCH chunked sort n=%zu big=%d (%s)\n", v.size(), big, what); std::exit(1); }
+      }
+    }
     ++arrays; elements += (long long)v.size();
   };
   auto make = [&](int n, int distinct, int shape) {
