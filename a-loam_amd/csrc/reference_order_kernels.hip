@@ -4,8 +4,8 @@
 // its (voxel index, point index) pairs in — up to 4 ulp apart in a centroid of three or more points, which the pipeline's discrete decisions amplify
 // into centimetres over hundreds of frames.  A context switched to the reference order runs these kernels instead of (mapping)
 // or after (registration: the values of the less-flat centroids are overwritten) the throughput filters: one workgroup per pcl::VoxelGrid::filter
-// call, the filter written out as PCL has it — bounding box, integer cell indices, index vector in input order, the sort REPLAYED step by step by
-// one lane (aloam_stdsort.hpp), members summed in the sorted order.  It is a validation mode: exact, an order of magnitude slower than the default.
+// call, the filter written out as PCL has it — bounding box, integer cell indices, index vector in input order, the sort REPLAYED swap for swap
+// (aloam_stdsort.hpp; sort_reference_order below), members summed in the sorted order.  It is a validation mode: exact, 4 - 12x slower than the default.
 //   reference: src/scanRegistration.cpp:392-407 (less-flat points of one ring), src/laserMapping.cpp:542-550 (incoming stacks), :788-801 (valid cubes)
 #include "aloam_stdsort.hpp"
 #include "mapping_kernels.hpp"
