@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--from-kitti", help="dataset_folder of kitti_helper.launch: write its lidar sweeps as a bag instead of running")
     ap.add_argument("--seq", default="00")
     ap.add_argument("--write-bag")
-    ap.add_argument("--reference-order", action="store_true", help="sum voxel members in pcl::VoxelGrid's own order (the reference's bits; ~15x slower): for runs that are compared pose by pose with A-LOAM's")
+    ap.add_argument("--reference-order", action="store_true", help="sum voxel members in pcl::VoxelGrid's own order (the reference's bits; ~4x slower for one sensor): for runs that are compared pose by pose with A-LOAM's")
     ap.add_argument("--selftest", action="store_true")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)

@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--mapping", action="store_true")
     ap.add_argument("--max-frames", type=int, default=0)
     ap.add_argument("--selftest", action="store_true")
-    ap.add_argument("--reference-order", action="store_true", help="sum voxel members in pcl::VoxelGrid's own order (the reference's bits; ~15x slower): for runs that are compared pose by pose with A-LOAM's")
+    ap.add_argument("--reference-order", action="store_true", help="sum voxel members in pcl::VoxelGrid's own order (the reference's bits; ~4x slower for one sensor): for runs that are compared pose by pose with A-LOAM's")
     ap.add_argument("--distortion", action="store_true", help="per-point interpolation ratio (the reference's DISTORTION 1; real KITTI sweeps are already de-skewed, so the reference ships 0)")
     args = ap.parse_args()
     if args.selftest:
