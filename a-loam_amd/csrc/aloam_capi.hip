@@ -249,7 +249,7 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   { ProfScope p(c, K_SCATTER); launch_scatter(a, c->stream); }
   if (slot >= 0) { HIP_TRY(c, hipEventRecord(c->in_consumed[slot], c->stream)); c->in_used[slot] = true; }   // the raw sweep is not read after this
   { ProfScope p(c, K_RING_FEATURES); launch_ring_features(a, c->npad, 0.2f, c->stream);     // leaf 0.2 (src/scanRegistration.cpp:404)
-    if (c->sum_order) launch_less_flat_reference_order(reg_args(c, d_scans, seq_stride, stride_bytes), 0.2f, c->stream); }
+    if (c->sum_order) launch_less_flat_reference_order(reg_args(c, d_scans, seq_stride, stride_bytes), c->npad, 0.2f, c->stream); }
   HIP_TRY(c, hipGetLastError());
   c->have_features = true;
   return ALOAM_OK;

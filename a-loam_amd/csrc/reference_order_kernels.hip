@@ -32,8 +32,9 @@ __device__ __forceinline__ float block_min(float v, float* s, int tid) {
 // data-parallel steps"): ranges of kBigRange elements and more are partitioned cooperatively - the two stop lists by ballot ranks, tile after tile, the
 // rank match, the independent swaps -, smaller ranges become chunks that single lanes finish (introsort loop + insertion sort of the stretch).
 //   fpos: n - 1 ints, lpos: n ints (global or LDS); s_work: 3 * kWorkMax ints, s_chunk: 3 * kChunkMax ints, s_i: >= 16 ints of LDS
-constexpr int kBigRange = 128, kWorkMax = 256, kChunkMax = 2048, kSeqSort = 96;
-__device__ void sort_reference_order(Entry* E, int n, int* fpos, int* lpos, int* s_work, int* s_chunk, int* s_i) {
+constexpr int kBigRange = 128, kWorkMax = 256, kChunkMax = 2048, kSeqSort = 96;   // list capacities of the mapping kernel (index vectors of any length)
+constexpr int kRingWorkMax = 48, kRingChunkMax = 160;                              // ... of the per-ring kernel (<= 4107 entries)
+__device__ void sort_reference_order(Entry* E, int n, int* fpos, int* lpos, int* s_work, int work_max, int* s_chunk, int chunk_max, int* s_i) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int stack[3 * 48];                                                         // private: pending ranges of one lane's introsort loop (depth <= 2 lg n <= 46 here)
   if (n <= kSeqSort) {                                                       // short index vectors: one lane, start to finish
@@ -52,10 +53,10 @@ __device__ void sort_reference_order(Entry* E, int n, int* fpos, int* lpos, int*
     const int sp = s_i[8] - 1;
     const int first = s_work[3 * sp], last = s_work[3 * sp + 1], depth = s_work[3 * sp + 2];
     __syncthreads();
-    if (last - first < kBigRange || depth == 0 || s_i[8] + 2 > kWorkMax) {   // a chunk (also: out of depth -> the lane heap-sorts it; work list full)
+    if (last - first < kBigRange || depth == 0 || s_i[8] + 2 > work_max) {   // a chunk (also: out of depth -> the lane heap-sorts it; work list full)
       if (tid == 0) {
         const int c = s_i[9];
-        if (c < kChunkMax) { s_chunk[3 * c] = first; s_chunk[3 * c + 1] = last; s_chunk[3 * c + 2] = depth; s_i[9] = c + 1; }
+        if (c < chunk_max) { s_chunk[3 * c] = first; s_chunk[3 * c + 1] = last; s_chunk[3 * c + 2] = depth; s_i[9] = c + 1; }
         else stdsort::finish_chunk(E, first, last, depth, stack);            // (chunk list full: finished on the spot)
         s_i[8] = sp;
       }
@@ -125,7 +126,7 @@ __device__ void sort_reference_order(Entry* E, int n, int* fpos, int* lpos, int*
 //   out        receives the centroids in ascending cell order; returns their number (n and nothing written when PCL returns its input unfiltered:
 //              more than INT_MAX cells in the bounding box)
 template <class PointFn>
-__device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, Entry* E, float4* out, float* s_f, int* s_i, int* s_work, int* s_chunk, int* fpos, int* lpos, bool* unfiltered) {
+__device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, Entry* E, float4* out, float* s_f, int* s_i, int* s_work, int work_max, int* s_chunk, int chunk_max, int* fpos, int* lpos, bool* unfiltered) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float inv = 1.0f / leaf;                            // inverse_leaf_size_
   float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
@@ -150,7 +151,7 @@ __device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, En
     E[i] = Entry{(unsigned)(i0 + i1 * mul1 + i2 * mul2), (unsigned)i};
   }
   __syncthreads();
-  sort_reference_order(E, n, fpos, lpos, s_work, s_chunk, s_i);   // std::sort(index_vector.begin(), index_vector.end(), std::less<cloud_point_index_idx>())
+  sort_reference_order(E, n, fpos, lpos, s_work, work_max, s_chunk, chunk_max, s_i);   // std::sort(index_vector.begin(), index_vector.end(), std::less<cloud_point_index_idx>())
   // one output point per run of equal cell indices; the members are summed in the order the sort left them
   int base = 0;
   for (int p0 = 0; p0 < n; p0 += kLitThreads) {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kLitThreads) void k_vox_reference_order(VoxArgs v, 
     int* lpos = fpos + n - 1;                                                // (at most S - 1 stops of f and S stops of l in a range of S <= n elements: 2 n - 1 ints)
     const float4* in = sg.in;
     bool unf;
-    const int n_vox = voxel_grid_reference_order([&](int i) { return in[i]; }, n, sg.leaf, E, sg.out, s_f, s_i, s_work, s_chunk, fpos, lpos, &unf);
+    const int n_vox = voxel_grid_reference_order([&](int i) { return in[i]; }, n, sg.leaf, E, sg.out, s_f, s_i, s_work, kWorkMax, s_chunk, kChunkMax, fpos, lpos, &unf);
     if (tid == 0) s_unfiltered = unf;
     __syncthreads();
     if (sg.final_out) {                                     // in-place cube filter: back over the cube once every member has been read
@@ -223,22 +224,22 @@ __global__ __launch_bounds__(kLitThreads) void k_vox_reference_order(VoxArgs v, 
 // Runs after k_ring_features, which has selected the features, written cloudLabel and the less-flat centroids (input order) at their final place and
 // published every ring's count: this kernel recomputes the VALUES of a ring's centroids in the reference's order and writes them over the others
 // (the cells, their order and their number are the same by construction; a different count is reported as an internal error).
-__global__ __launch_bounds__(kLitThreads) void k_less_flat_reference_order(RegArgs a, float leaf) {
+__global__ __launch_bounds__(kLitThreads) void k_less_flat_reference_order(RegArgs a, float leaf, int max_ring) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lit_smem[];
   const int b = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int start = a.ringstart[b * (a.R + 1) + r];
   const int n = a.ringstart[b * (a.R + 1) + r + 1] - start;
   const int L = n - 11;                                     // elements scanStartInd .. scanEndInd - 1 (:249-251,284-285)
   if (L < 6) return;                                        // :279
-  constexpr int kMaxRing = 4107;
+  const int kMaxRing = max_ring;                            // 2059 or 4107 (the context's max_ring_points class)
   if (n > kMaxRing) return;                                 // k_ring_features has flagged the sweep (kErrRingCap)
-  Entry* E = reinterpret_cast<Entry*>(lit_smem);            // [kMaxRing]
-  unsigned short* member = reinterpret_cast<unsigned short*>(E + kMaxRing);   // [kMaxRing] element of the m-th member
-  int* fpos = reinterpret_cast<int*>(member + kMaxRing + 1);                  // [kMaxRing + 1] x 2
+  Entry* E = reinterpret_cast<Entry*>(lit_smem);            // [kMaxRing + 1]
+  int* fpos = reinterpret_cast<int*>(E + kMaxRing + 1);     // [kMaxRing + 1] x 2
   int* lpos = fpos + kMaxRing + 1;
   int* s_work = lpos + kMaxRing + 1;
-  int* s_chunk = s_work + 3 * kWorkMax;
-  float* s_f = reinterpret_cast<float*>(s_chunk + 3 * kChunkMax);
+  int* s_chunk = s_work + 3 * kRingWorkMax;
+  float* s_f = reinterpret_cast<float*>(s_chunk + 3 * kRingChunkMax);
+  unsigned short* member = reinterpret_cast<unsigned short*>(s_f + 8 + 24);   // [kMaxRing + 1] element of the m-th member (behind s_i)
   int* s_i = reinterpret_cast<int*>(s_f + 8);
   const float4* cloud = a.cloud + (long long)b * a.cap + start + 5;
   const int8_t* label = a.label + (long long)b * a.cap + start + 5;
@@ -271,17 +272,19 @@ __global__ __launch_bounds__(kLitThreads) void k_less_flat_reference_order(RegAr
   if (n_mem == 0) return;
   bool unf;
   float4* out = a.less_flat + (long long)b * a.cap + off;
-  const int n_vox = voxel_grid_reference_order([&](int i) { return cloud[member[i]]; }, n_mem, leaf, E, out, s_f, s_i, s_work, s_chunk, fpos, lpos, &unf);
+  const int n_vox = voxel_grid_reference_order([&](int i) { return cloud[member[i]]; }, n_mem, leaf, E, out, s_f, s_i, s_work, kRingWorkMax, s_chunk, kRingChunkMax, fpos, lpos, &unf);
   if (tid == 0 && (unf || n_vox != expect)) atomicOr(&a.meta[b].err, kErrInternal);
 }
 
-void launch_less_flat_reference_order(const RegArgs& a, float leaf, hipStream_t s) {
-  const size_t lds = sizeof(Entry) * 4107 + sizeof(unsigned short) * 4108 + sizeof(int) * (2 * 4108 + 3 * kWorkMax + 3 * kChunkMax + 24);
-  hipLaunchKernelGGL(k_less_flat_reference_order, dim3(a.B, a.R), dim3(kLitThreads), lds, s, a, leaf);
+void launch_less_flat_reference_order(const RegArgs& a, int npad, float leaf, hipStream_t s) {
+  const int max_ring = npad + 11;                           // the ring capacity k_ring_features<NPAD> was launched with
+  const size_t lds = sizeof(Entry) * (max_ring + 1) + sizeof(int) * (2 * (max_ring + 1) + 3 * kRingWorkMax + 3 * kRingChunkMax + 8 + 24) + sizeof(unsigned short) * (max_ring + 2);
+  hipLaunchKernelGGL(k_less_flat_reference_order, dim3(a.B, a.R), dim3(kLitThreads), lds, s, a, leaf, max_ring);
 }
 
 static size_t vox_reference_lds_bytes() { return sizeof(Entry) * kLitLdsEntries + sizeof(int) * (3 * kWorkMax + 3 * kChunkMax + 24); }
 int prepare_reference_order() {
+  if (hipFuncSetAttribute((const void*)k_less_flat_reference_order, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return -1;
   return hipFuncSetAttribute((const void*)k_vox_reference_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_reference_lds_bytes()) == hipSuccess ? 0 : -1;
 }
 void launch_voxel_filter_reference_order(const VoxArgs& v, const MapArgs& a, bool stacks, hipStream_t s) {

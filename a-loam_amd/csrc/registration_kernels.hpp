@@ -9,5 +9,5 @@ void launch_classify(const RegArgs& a, hipStream_t s);
 void launch_ring_offsets(const RegArgs& a, hipStream_t s);
 void launch_scatter(const RegArgs& a, hipStream_t s);
 void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s);
-void launch_less_flat_reference_order(const RegArgs& a, float leaf, hipStream_t s);   // reference_order_kernels.hip
+void launch_less_flat_reference_order(const RegArgs& a, int npad, float leaf, hipStream_t s);   // reference_order_kernels.hip
 }  // namespace aloam

@@ -95,7 +95,7 @@ int aloam_synchronize(aloam_ctx* ctx);                               /* waits + 
 /* pcl::VoxelGrid (src/scanRegistration.cpp:402-405, src/laserMapping.cpp:543-549,793-799) sums the members of a voxel in the order an UNSTABLE
  * std::sort leaves its index vector in.  ALOAM_SUM_INPUT_ORDER (default, the throughput path) sums them in input order: centroids of three or more
  * points may differ from the reference's in their last bits (<= 4 ulp), nothing else does.  ALOAM_SUM_REFERENCE_ORDER replays libstdc++'s introsort
- * on the device (one workgroup per filter call) and sums in the order it produces: the reference's bits, 4x (one sensor) to 12x (large batches) slower -
+ * on the device (one workgroup per filter call) and sums in the order it produces: the reference's bits, about 4x slower (registration + odometry; more with mapping at large batches) -
  * a validation mode for comparing long free-running sequences with the reference's own output.  Takes effect from the next call; not to be changed mid-sequence. */
 enum { ALOAM_SUM_INPUT_ORDER = 0, ALOAM_SUM_REFERENCE_ORDER = 1 };
 int aloam_set_voxel_sum_order(aloam_ctx* ctx, int order);
