@@ -186,24 +186,27 @@ __device__ int voxel_grid_reference_order(PointFn&& point, int n, float leaf, En
 // ---- mapping: every VoxSeg of the list (incoming stacks / valid cubes) -------------------------------------------------------------------------
 // scratch: 8 bytes per input point for index vectors that do not fit the LDS: the general voxel path's key buffer, addressed like the segment's
 // output (stacks: by sequence and class; cubes: the cube's own range of the pool-sized staging buffer, where `out` already points)
-__global__ __launch_bounds__(kLitThreads) void k_vox_reference_order(VoxArgs v, MapArgs a, int stacks) {
+// A launch takes the segments with n_lo < n <= n_hi and keeps index vectors of up to lds_entries entries in LDS: one launch with 16 384 for a single
+// sensor (latency), two for batches - short vectors in 16 KiB of LDS, five workgroups per CU, and long ones in global scratch with the lists alone in LDS,
+// instead of one 146 KiB workgroup per CU.
+__global__ __launch_bounds__(kLitThreads) void k_vox_reference_order(VoxArgs v, MapArgs a, int stacks, int lds_entries, int n_lo, int n_hi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lit_smem[];
-  Entry* lds_E = reinterpret_cast<Entry*>(lit_smem);
-  int* s_work = reinterpret_cast<int*>(lit_smem + sizeof(Entry) * kLitLdsEntries);
+  int* s_work = reinterpret_cast<int*>(lit_smem);
   int* s_chunk = s_work + 3 * kWorkMax;
   float* s_f = reinterpret_cast<float*>(s_chunk + 3 * kChunkMax);
   int* s_i = reinterpret_cast<int*>(s_f + 8);
+  Entry* lds_E = reinterpret_cast<Entry*>(s_i + 24);
   __shared__ bool s_unfiltered;
   const int tid = threadIdx.x;
   for (int g = blockIdx.x; g < v.n_segs; g += gridDim.x) {
     __syncthreads();
     const VoxSeg sg = v.segs[g];
     const int n = sg.n;
-    if (n <= 0) continue;
+    if (n <= n_lo || n > n_hi) continue;
     long long soff;
     if (stacks) { const int b = g >> 1; soff = (long long)b * ((long long)a.cap + a.R * 120) + ((g & 1) ? a.R * 120 : 0); }
     else soff = sg.out - v.tmp;
-    Entry* E = n <= kLitLdsEntries ? lds_E : reinterpret_cast<Entry*>(v.keys[0]) + soff;
+    Entry* E = n <= lds_entries ? lds_E : reinterpret_cast<Entry*>(v.keys[0]) + soff;
     int* fpos = reinterpret_cast<int*>(v.keys[1] + soff);                    // the two stop lists of a cooperative partition: 2 x 4 bytes per point of the second key buffer
     int* lpos = fpos + n - 1;                                                // (at most S - 1 stops of f and S stops of l in a range of S <= n elements: 2 n - 1 ints)
     const float4* in = sg.in;
@@ -282,14 +285,20 @@ void launch_less_flat_reference_order(const RegArgs& a, int npad, float leaf, hi
   hipLaunchKernelGGL(k_less_flat_reference_order, dim3(a.B, a.R), dim3(kLitThreads), lds, s, a, leaf, max_ring);
 }
 
-static size_t vox_reference_lds_bytes() { return sizeof(Entry) * kLitLdsEntries + sizeof(int) * (3 * kWorkMax + 3 * kChunkMax + 24); }
+static size_t vox_reference_lds_bytes(int lds_entries) { return sizeof(Entry) * (size_t)lds_entries + sizeof(int) * (3 * kWorkMax + 3 * kChunkMax + 8 + 24); }
 int prepare_reference_order() {
   if (hipFuncSetAttribute((const void*)k_less_flat_reference_order, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return -1;
-  return hipFuncSetAttribute((const void*)k_vox_reference_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_reference_lds_bytes()) == hipSuccess ? 0 : -1;
+  return hipFuncSetAttribute((const void*)k_vox_reference_order, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vox_reference_lds_bytes(kLitLdsEntries)) == hipSuccess ? 0 : -1;
 }
 void launch_voxel_filter_reference_order(const VoxArgs& v, const MapArgs& a, bool stacks, hipStream_t s) {
-  const int grid = v.n_segs < 8192 ? v.n_segs : 8192;
-  hipLaunchKernelGGL(k_vox_reference_order, dim3(grid), dim3(kLitThreads), vox_reference_lds_bytes(), s, v, a, stacks ? 1 : 0);
+  const int grid = v.n_segs < 16384 ? v.n_segs : 16384;
+  if (a.B < 16) {
+    hipLaunchKernelGGL(k_vox_reference_order, dim3(grid), dim3(kLitThreads), vox_reference_lds_bytes(kLitLdsEntries), s, v, a, stacks ? 1 : 0, kLitLdsEntries, 0, 0x7fffffff);
+    return;
+  }
+  constexpr int kSmall = 2048;
+  hipLaunchKernelGGL(k_vox_reference_order, dim3(grid), dim3(kLitThreads), vox_reference_lds_bytes(0), s, v, a, stacks ? 1 : 0, 0, kSmall, 0x7fffffff);   // the long ones first
+  hipLaunchKernelGGL(k_vox_reference_order, dim3(grid), dim3(kLitThreads), vox_reference_lds_bytes(kSmall), s, v, a, stacks ? 1 : 0, kSmall, 0, kSmall);
 }
 
 }  // namespace aloam
