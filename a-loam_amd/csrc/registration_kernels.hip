@@ -456,8 +456,17 @@ __device__ __forceinline__ void pick_sector(int j, unsigned init_marks, int L, i
 }
 
 
-// markers in the generated code for tools/isa_phases.py (comments only: no instruction is emitted)
+// markers in the generated code for tools/isa_phases.py (comments only: no instruction is emitted).  Debug builds (-DALOAM_PHASE_CLOCK): wave 0 of every
+// workgroup also adds the shader clock at the marker to a per-marker sum, so the mean time BETWEEN two markers over a run is a difference of two sums
+// divided by the count (tools/ab_check.py prints it); the product build emits nothing.
+#ifdef ALOAM_PHASE_CLOCK
+__device__ unsigned long long g_phase_clock[2][32];
+constexpr int phase_slot(const char* s) { unsigned h = 0; while (*s) h = h * 33u + (unsigned char)*s++; return (int)(h % 32u); }   // collision-free over the markers of this file (tools/ab_check.py checks)
+#define ALOAM_PHASE(name) do { asm volatile("; ##PHASE " name); if (threadIdx.x == 0) { constexpr int slot_ = phase_slot(name); \
+    atomicAdd(&g_phase_clock[0][slot_], (unsigned long long)__builtin_readcyclecounter()); atomicAdd(&g_phase_clock[1][slot_], 1ull); } } while (0)
+#else
 #define ALOAM_PHASE(name) asm volatile("; ##PHASE " name)
+#endif
 // cloudLabel (2 sharp, 1 less sharp, 0, -1 flat) shares the per-point flag byte with the reach of the neighbour suppression: bits 0-1 hold the
 // label code (2, 1, 0, 3 = -1), bits 2-7 the reach during the selection and, afterwards, bit 2 the "continues the run of its predecessor" mark of
 // the voxel filter.  One byte array less per ring is what lets EIGHT ring workgroups share a CU's LDS (20.2 KB each) instead of seven.
@@ -567,12 +576,23 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
       const K kq = rkeys[q];
       if ((unsigned)(kq >> SHIFT) != vi) break;
       int e = (int)((unsigned)kq & kEMask);
+      // The additions are a sequential chain (f32, input order) but the loads are not: a run is fetched four elements at a time, speculatively (the
+      // elements behind a run's end are loaded and dropped; L >= 6 and e + 8 <= L + 7 < n keep the addresses inside the ring), so a run of k elements
+      // costs ceil(k / 4) memory round trips instead of k.  The ring left the L2 while its selection ran: these are HBM / MALL latencies.
+      bool more;
       do {
-        const float4 pt = cloud[e + 5];
-        sx += pt.x; sy += pt.y; sz += pt.z; si += pt.w;
-        ++cnt;
-        ++e;
-      } while (e < L && (flags[e + 5] & 4));                                  // the run stops at the next head or non-member
+        const float4 p0 = cloud[e + 5], p1 = cloud[e + 6], p2 = cloud[e + 7], p3 = cloud[e + 8];
+        const bool c1 = e + 1 < L && (flags[e + 6] & 4), c2 = e + 2 < L && (flags[e + 7] & 4), c3 = e + 3 < L && (flags[e + 8] & 4);
+        more = e + 4 < L && (flags[e + 9] & 4);                               // the run stops at the next head or non-member
+        sx += p0.x; sy += p0.y; sz += p0.z; si += p0.w; ++cnt;
+        if (!c1) break;
+        sx += p1.x; sy += p1.y; sz += p1.z; si += p1.w; ++cnt;
+        if (!c2) break;
+        sx += p2.x; sy += p2.y; sz += p2.z; si += p2.w; ++cnt;
+        if (!c3) break;
+        sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w; ++cnt;
+        e += 4;
+      } while (more);
     }
     const float fc = (float)cnt;
     out[vrank[it]] = make_float4(sx / fc, sy / fc, sz / fc, si / fc);
@@ -581,8 +601,12 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
   return n_vox;
 }
 
+// Eight ring workgroups share a CU's LDS (20.2 KB each), i.e. eight waves per SIMD - if the registers allow it, and that includes the SCALAR ones: a gfx9 SIMD
+// has 800 SGPRs, a wave with more than 100 of them (the kernel used 106) is one of seven.  Telling the allocator the target (amdgpu_waves_per_eu) costs no spill
+// (62 VGPRs / 78 SGPRs) and took the kernel from 2.43 to 2.07 ms at batch 1024; fetching the ring further ahead (2, 3, 5, 8 chunks in registers) on top of it
+// changed nothing (2.06 - 2.08 ms).  The <4096> instance is limited to four workgroups by its LDS.
 template <int NPAD>
-__global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPAD <= 2048 ? 8 : 4))) void k_ring_features(RegArgs a, float leaf) {
   constexpr int MAXN = NPAD + 11;
   constexpr int ITEMS = (MAXN + 255) / 256;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;   // ring-major over the batch, see voxel_runs_tail
@@ -610,6 +634,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
   }
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  ALOAM_PHASE("ticket_taken");
   // region A (aliased over time): two 266-point xyz tiles during the curvature pass, then the curvature per point, then the voxel
   // index per element, then the run keys.  Keeping it at 8 * NPAD bytes is what lets seven workgroups share a CU's LDS.
   constexpr int A_BYTES = 8 * NPAD + 128;                                     // + room for the packed voxel cells behind the curvatures
@@ -902,9 +927,10 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
     voxel_runs_tail<NPAD, unsigned long long, 32>(smem, flags, s_scan, s_misc, cloud, out, L, tid, lane, wave, lb + 3 * a.R, r, a.R, a.epoch, &a.meta[b].err);
   // the picked points go straight to their final place in the three clouds, in the reference's order (ring, sector, pick order;
   // sharp = the first two less-sharp picks, :301-311)
-  if (wave == 0) {
+  {                                                                          // one slot per thread: a single memory round trip for the whole ring
     const int base_sharp = s_misc[40], base_less = s_misc[41], base_flat = s_misc[42];
-    for (int q = lane; q < kSectors * kSlots; q += 64) {
+    static_assert(kSectors * kSlots <= 256, "one thread per pick slot");
+    if (const int q = tid; q < kSectors * kSlots) {
       const int j = q / kSlots, slot = q % kSlots;
       const int ncorner = s_misc[1 + j] & 0xff, nflat = s_misc[1 + j] >> 8;
       if (slot < kSharpPerSector) {
@@ -918,6 +944,7 @@ __global__ __launch_bounds__(256) void k_ring_features(RegArgs a, float leaf) {
       }
     }
   }
+  ALOAM_PHASE("picks_out");
 }
 
 // Sizes of the four feature clouds of every sweep = sums of the published ring counts (one wave per sweep).
@@ -950,3 +977,7 @@ void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s)
 }
 
 }  // namespace aloam
+
+#ifdef ALOAM_PHASE_CLOCK
+extern "C" int aloam_debug_phase_clock(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(aloam::g_phase_clock), sizeof(unsigned long long) * 64); }
+#endif

@@ -156,6 +156,27 @@ def run(argv):
         for cls in (0, 1):
             q = max(1, st[cls * 32 + 1])
             print("corner" if cls == 0 else "plane", {names[i]: round(st[cls * 32 + i] / q, 3) for i in sorted(names)}, "queries", st[cls * 32 + 1])
+    if hasattr(L, "aloam_debug_phase_clock"):                   # -DALOAM_PHASE_CLOCK builds: mean shader-clock time between the phase markers of k_ring_features
+        st = (C.c_ulonglong * 64)()
+        L.aloam_debug_phase_clock(st)
+        names = ["ticket_taken", "after_curvature", "after_reach", "after_select1", "after_redo_labels_counts", "after_bbox_voxidx", "after_run_heads", "after_sort",
+                 "after_vox_heads_gather", "after_centroids", "picks_out"]
+
+        def slot(s):
+            h = 0
+            for c in s.encode():
+                h = (h * 33 + c) & 0xffffffff
+            return h % 32
+        assert len({slot(n) for n in names}) == len(names)
+        cnt = [st[32 + slot(n)] for n in names]
+        print("phase clock: workgroups per marker", cnt)
+        tot = 0.0
+        for a_, b_ in zip(names[:-1], names[1:]):
+            if st[32 + slot(a_)] == st[32 + slot(b_)] and st[32 + slot(a_)]:
+                d = ((st[slot(b_)] - st[slot(a_)]) & (2 ** 64 - 1)) / st[32 + slot(a_)]
+                tot += d
+                print(f"  {a_:28s} -> {b_:28s} {d:12.0f} clocks")
+        print(f"  total {tot:.0f} clocks per workgroup")
     if mapping and "--cube-hist" in argv:                        # sizes of the map cubes the per-cube re-filter works on (k_vox_lds instances: <= 2048 / <= 8192 / <= 65536 points)
         L.aloam_map_cube_counts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         for b in watch:
