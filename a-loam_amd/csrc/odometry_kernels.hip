@@ -30,6 +30,12 @@ namespace aloam {
 
 // markers in the generated code for tools/isa_phases.py (comments only: no instruction is emitted)
 #define ALOAM_PHASE(name) asm volatile("; ##PHASE " name)
+#ifdef ALOAM_PHASE_CLOCK   // debug builds: shader clock at numbered points of k_build_grids_fused (surf class), summed over the workgroups (tools/ab_check.py)
+__device__ unsigned long long g_phase_clock_odo[2][32];
+#define ALOAM_BG_CLOCK(slot) do { if (threadIdx.x == 0 && blockIdx.x == 1) { atomicAdd(&g_phase_clock_odo[0][slot], (unsigned long long)__builtin_readcyclecounter()); atomicAdd(&g_phase_clock_odo[1][slot], 1ull); } } while (0)
+#else
+#define ALOAM_BG_CLOCK(slot) do { } while (0)
+#endif
 // debug builds (-DALOAM_ASSOC_STATS): what the association waves actually do, summed over a run (tools/ab_check.py stats)
 #ifdef ALOAM_ASSOC_STATS
 __device__ unsigned long long g_assoc_stats[2][32];
@@ -216,9 +222,11 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
     if (tid < 3) g.flags[tid] = 0;
     return;
   }
+  ALOAM_BG_CLOCK(0);
   for (int w = tid; w < 3 * (H / 2); w += 1024) tab[w] = 0u;
   if (tid < 2) s_flag[tid] = 0;
   __syncthreads();
+  ALOAM_BG_CLOCK(1);
   const float inv0 = 1.0f / cell3_of(which), inv1 = 1.0f / (cell3_of(which) * kCell3CoarseFactor), inv2 = 1.0f / kCell2;
   const unsigned hm = (unsigned)(H - 1);
   auto buckets = [&](const float4& p, int key, unsigned* h) {
@@ -255,8 +263,10 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
     if (unsorted) atomicOr(&s_flag[1], 1);
   }
   __syncthreads();
+  ALOAM_BG_CLOCK(2);
   if (s_flag[1] && !s_flag[0]) walk_tables(pts, n, a.R, g.walk, s_walk, s_flag, tid);    // some key is lower than its predecessor's: nearly sorted or not at all?
   if (tid < 3) g.flags[tid] = tid == 2 ? 0 : s_flag[tid];
+  ALOAM_BG_CLOCK(3);
   // ---- exclusive scans of the three tables: every thread owns H / 1024 consecutive buckets (= H / 2048 words) of each
   {
     const int wpt = H / 2048;                                              // words per thread and table (2 at H = 4096, 8 at 16384)
@@ -286,7 +296,10 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
     }
   }
   __syncthreads();
-  // ---- fill: the three copies of every point from one read
+  ALOAM_BG_CLOCK(4);
+  // ---- fill: the three copies of every point from one read.  (Measured in round 6, phase clock: count 90 k cycles, scans 26 k, fill 360 k of a surf
+  // workgroup's 480 k.  The fill is bound by what it writes - 3 x 16 B per point to scattered places, ~2.9 TB/s over the chip while it runs - not by the LDS
+  // atomics: handing the positions out per RUN of equal buckets, one atomic per run, changed nothing: 1.392 / 1.522 against 1.363 / 1.485 ms.)
   for (int base = 0; base < n; base += U * 1024) {
     float4 p[U];
     fetch(base, p);
@@ -309,6 +322,11 @@ __global__ __launch_bounds__(1024) void k_build_grids_fused(OdomArgs a) {
       g.sorted2[pos[2]] = e;
     }
   }
+  ALOAM_BG_CLOCK(5);
+#ifdef ALOAM_PHASE_CLOCK
+  __syncthreads();
+  ALOAM_BG_CLOCK(6);
+#endif
 }
 
 constexpr int kBgWaves = 4;   // waves per SIMD the register budget is sized for
@@ -1504,6 +1522,9 @@ void launch_solve(const OdomArgs& a, hipStream_t s) {
 
 }  // namespace aloam
 
+#ifdef ALOAM_PHASE_CLOCK
+extern "C" int aloam_debug_phase_clock_odo(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(aloam::g_phase_clock_odo), sizeof(unsigned long long) * 64); }
+#endif
 #ifdef ALOAM_ASSOC_STATS
 extern "C" int aloam_debug_assoc_stats(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(aloam::g_assoc_stats), sizeof(unsigned long long) * 64); }
 #endif

@@ -525,7 +525,7 @@ __device__ __forceinline__ int voxel_runs_tail(unsigned char* smem, unsigned cha
     if ((hmask >> it) & 1u) { const int e = it * 256 + tid; rkeys[hrank[it]] = (K)(((K)myvi[it] << SHIFT) | (K)e); }   // vis is dead: every thread read its share before the barrier
   __syncthreads();
   ALOAM_PHASE("after_run_heads");   // run heads + keys
-  bitonic_sort_keys<K>(rkeys, n_runs, tid);      // (a radix sort of the run keys - 9 instead of ~40 barriers, half the VALU work - was measured twice and lost, 2.48 against 2.43 ms: HISTORY.md)
+  bitonic_sort_keys<K>(rkeys, n_runs, tid);      // (a radix sort of the run keys - 9 instead of ~40 barriers, half the VALU work - was measured three times and lost, last at eight waves per SIMD: 2.25 against 2.15 ms: HISTORY.md)
 
   ALOAM_PHASE("after_sort");   // sort
   // voxel heads among the sorted runs -> output rank (ascending voxel index), centroid = f32 sums in input order / count

@@ -177,6 +177,13 @@ def run(argv):
                 tot += d
                 print(f"  {a_:28s} -> {b_:28s} {d:12.0f} clocks")
         print(f"  total {tot:.0f} clocks per workgroup")
+    if hasattr(L, "aloam_debug_phase_clock_odo"):               # the same for k_build_grids_fused (surf class): numbered points
+        st = (C.c_ulonglong * 64)()
+        L.aloam_debug_phase_clock_odo(st)
+        names = ["entry", "tables zeroed", "counted", "flags / walk tables", "scanned", "filled (thread 0)", "filled (all)"]
+        for i in range(1, len(names)):
+            if st[32 + i] and st[32 + i] == st[32 + i - 1]:
+                print(f"  grid build  {names[i - 1]:22s} -> {names[i]:22s} {((st[i] - st[i - 1]) & (2 ** 64 - 1)) / st[32 + i]:12.0f} clocks")
     if mapping and "--cube-hist" in argv:                        # sizes of the map cubes the per-cube re-filter works on (k_vox_lds instances: <= 2048 / <= 8192 / <= 65536 points)
         L.aloam_map_cube_counts.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         for b in watch:
