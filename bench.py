@@ -314,7 +314,13 @@ def roofline_of(prof, steps, B, sensor, mapping):
          "whole_step": {"algorithmic_bytes": step_bytes, "kernel_ms": round(step_ms, 4),
                         "achieved_gbs": round(step_bytes / (step_ms * 1e-3) / 1e9, 2) if step_ms > 0 else 0.0,
                         "frac": round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if step_ms > 0 else 0.0},
-         "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in prof.items() if v["launches"]}}
+         "kernels_ms_per_step": {k: round(v["total_ms"] / steps, 4) for k, v in prof.items() if v["launches"]},
+         # the same view of every profiled kernel (algorithmic bytes per launch / mean launch time against HBM peak): the dominant one changes hands between
+         # k_ring_features and the planar association (two launches per step) from box to box
+         "per_kernel": {k: {"avg_launch_ms": round(v["total_ms"] / v["launches"], 4), "launches_per_step": round(v["launches"] / max(1, steps), 2),
+                            "achieved": round(v["bytes_per_launch"] / (v["total_ms"] / v["launches"] * 1e-3) / 1e9, 1),
+                            "frac": round(v["bytes_per_launch"] / (v["total_ms"] / v["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                        for k, v in prof.items() if v["launches"] and v["total_ms"] > 0}}
     # HBM traffic of the dominant kernel from the separate rocprofv3 --pmc passes of THIS command (tools/gpu_pmc.sh;
     # MI355X_MICROARCH.md: counters in their own passes; FETCH_SIZE [KiB] reports half the bytes of wide coalesced reads on
     # gfx950 -> doubled; WRITE_SIZE [KiB] as reported).  Only attached when the profiled configuration is this one.
