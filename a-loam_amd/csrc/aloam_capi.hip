@@ -22,7 +22,7 @@ namespace {
 enum KernelId { K_FIND_ENDS = 0, K_CLASSIFY, K_RING_OFFSETS, K_SCATTER, K_RING_FEATURES, K_BUILD_GRIDS, K_TRANSFORM, K_ASSOC_CORNER,
                 K_ASSOC_PLANE, K_SOLVE, K_ADVANCE, K_MAP_BEGIN, K_MAP_VOXEL_STACK, K_MAP_GRID, K_MAP_ASSOC, K_MAP_SOLVE, K_MAP_INSERT,
                 K_MAP_VOXEL_CUBES, K_MAP_REGISTER, K_COUNT };
-const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_classify", "k_ring_offsets", "k_scatter", "k_ring_features",
+const char* kKernelNames[K_COUNT] = {"k_find_ends", "k_front", "k_ring_starts", "k_dense_cloud", "k_ring_features",
                                      "k_build_grids", "k_transform_queries", "k_associate[corner]", "k_associate[plane]",
                                      "k_solve", "k_advance", "map_begin", "map_voxel[stacks]", "map_grid", "map_associate", "map_solve",
                                      "map_insert", "map_voxel[cubes]", "map_register"};
@@ -47,8 +47,10 @@ struct aloam_ctx {
   int* h_nin = nullptr; int h_nin_slot = 0;         // pinned ring of kNinSlots x B counts: an async H2D copy reads its slot later
   hipEvent_t nin_done[8] = {}; bool nin_used[8] = {};
   SeqMeta* d_meta = nullptr;
-  int8_t* d_ringid = nullptr; float* d_ori = nullptr;
-  int *d_hist = nullptr, *d_blockoff = nullptr, *d_ringstart = nullptr;
+  float4* d_slabs = nullptr; int slab = 0;          // ring-ordered points, one slab per (sequence, ring): what k_front writes and the feature kernels read
+  unsigned long long* d_front_lb = nullptr; int* d_front_ticket = nullptr;
+  bool dense_valid = true;                          // d_cloud holds the dense concatenation of the current slabs (k_dense_cloud, on demand)
+  int* d_ringstart = nullptr;
   float4* d_cloud = nullptr; float* d_curv = nullptr; int8_t* d_label = nullptr;
   unsigned long long* d_lookback = nullptr; unsigned reg_epoch = 0;   // ring-count granules of k_ring_features, launch counter
   int* d_ring_ticket = nullptr;                                       // per sweep: rings handed out to the workgroups of the running k_ring_features
@@ -175,11 +177,20 @@ RegArgs reg_args(aloam_ctx* c, const void* d_scans, long long seq_stride, int pt
   a.in = (const char*)d_scans; a.seq_stride = seq_stride; a.pt_stride = pt_stride;
   a.B = c->B; a.cap = c->cap; a.R = c->R; a.NB = c->NB;
   a.ring_from_field = c->cfg.ring_from_field; a.min_range = c->cfg.min_range;
-  a.meta = c->d_meta; a.ringid = c->d_ringid; a.ori = c->d_ori; a.hist = c->d_hist; a.blockoff = c->d_blockoff;
+  a.meta = c->d_meta; a.slabs = c->d_slabs; a.slab = c->slab; a.front_lb = c->d_front_lb; a.front_ticket = c->d_front_ticket;
   a.ringstart = c->d_ringstart; a.cloud = c->d_cloud; a.curv = c->d_curv; a.label = c->d_label;
   a.lookback = c->d_lookback; a.epoch = c->reg_epoch; a.store_debug = c->debug_arrays ? 1 : 0; a.ring_ticket = c->d_ring_ticket;
   a.sharp = c->d_sharp; a.less_sharp = c->d_less_sharp[c->cur]; a.flat = c->d_flat; a.less_flat = c->d_less_flat[c->cur];
   return a;
+}
+
+// The dense ring-by-ring cloud (laserCloud of src/scanRegistration.cpp:246-252) is made from the slabs when a consumer of the FULL cloud asks for it.
+int ensure_dense(aloam_ctx* c) {
+  if (c->dense_valid) return ALOAM_OK;                  // (also: nothing registered yet, or the cloud was set from outside)
+  { ProfScope p(c, K_SCATTER); launch_dense_cloud(reg_args(c, nullptr, 0, 16), c->stream); }
+  HIP_TRY(c, hipGetLastError());
+  c->dense_valid = true;
+  return ALOAM_OK;
 }
 
 OdomArgs odom_args(aloam_ctx* c) {
@@ -241,12 +252,12 @@ int register_launch(aloam_ctx* c, const void* d_scans, long long seq_stride, con
   HIP_TRY(c, hipEventRecord(c->nin_done[ns], c->stream));
   c->nin_used[ns] = true;
   c->debug_arrays = debug_arrays || c->sum_order != 0;      // the reference-order pass reads cloudLabel
-  if (++c->reg_epoch == 0) c->reg_epoch = 1;
+  if (((++c->reg_epoch) & 0x7fffffffu) == 0) ++c->reg_epoch;                 // 31 bits of it tag the look-back granules; 0 = "never written"
   const RegArgs a = reg_args(c, d_scans, seq_stride, stride_bytes);
   { ProfScope p(c, K_FIND_ENDS); launch_find_ends(a, c->d_nin, c->stream); }
-  { ProfScope p(c, K_CLASSIFY); launch_classify(a, c->stream); }
-  { ProfScope p(c, K_RING_OFFSETS); launch_ring_offsets(a, c->stream); }
-  { ProfScope p(c, K_SCATTER); launch_scatter(a, c->stream); }
+  { ProfScope p(c, K_CLASSIFY); launch_front(a, c->stream); }
+  { ProfScope p(c, K_RING_OFFSETS); launch_ring_starts(a, c->stream); }
+  c->dense_valid = false;
   if (slot >= 0) { HIP_TRY(c, hipEventRecord(c->in_consumed[slot], c->stream)); c->in_used[slot] = true; }   // the raw sweep is not read after this
   { ProfScope p(c, K_RING_FEATURES); launch_ring_features(a, c->npad, 0.2f, c->stream);     // leaf 0.2 (src/scanRegistration.cpp:404)
     if (c->sum_order) launch_less_flat_reference_order(reg_args(c, d_scans, seq_stride, stride_bytes), c->npad, 0.2f, c->stream); }
@@ -318,10 +329,10 @@ int aloam_create_stages(const aloam_config* cfg, int stages, aloam_ctx** out) {
   if ((rc = dmalloc(c, &c->d_state, B))) return rc;
   if ((rc = dmalloc(c, &c->d_cloud, B * cap))) return rc;                    // /velodyne_cloud_2 -> _3 -> mapping's full-resolution input
   if (reg) {                                                                 // working set of scan registration
-    if ((rc = dmalloc(c, &c->d_ringid, B * cap))) return rc;
-    if ((rc = dmalloc(c, &c->d_ori, B * cap))) return rc;
-    if ((rc = dmalloc(c, &c->d_hist, B * NB * R))) return rc;
-    if ((rc = dmalloc(c, &c->d_blockoff, B * NB * R))) return rc;
+    c->slab = c->npad + 16;                                                  // >= the longest ring k_ring_features accepts (npad + 11)
+    if ((rc = dmalloc(c, &c->d_slabs, B * R * (size_t)c->slab))) return rc;
+    if ((rc = dmalloc(c, &c->d_front_lb, B * NB * (size_t)kFrontSlots))) return rc;
+    if ((rc = dmalloc(c, &c->d_front_ticket, B))) return rc;
     if ((rc = dmalloc(c, &c->d_ringstart, B * (R + 1)))) return rc;
     if ((rc = dmalloc(c, &c->d_curv, B * cap))) return rc;
     if ((rc = dmalloc(c, &c->d_label, B * cap))) return rc;
@@ -373,7 +384,7 @@ void aloam_destroy(aloam_ctx* c) {
   for (hipGraphExec_t& ge : c->odom_graph) if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
   for (hipEvent_t e : c->prof_free) (void)hipEventDestroy(e);
   if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-  void* bufs[] = {c->d_in[0], c->d_in[1], c->d_nin, c->d_meta, c->d_ringid, c->d_ori, c->d_hist, c->d_blockoff, c->d_ringstart, c->d_cloud, c->d_curv,
+  void* bufs[] = {c->d_in[0], c->d_in[1], c->d_nin, c->d_meta, c->d_slabs, c->d_front_lb, c->d_front_ticket, c->d_ringstart, c->d_cloud, c->d_curv,
                   c->d_label, c->d_lookback, c->d_ring_ticket, c->d_sharp,
                   c->d_flat, c->d_less_sharp[0], c->d_less_sharp[1], c->d_less_flat[0], c->d_less_flat[1], c->d_state, c->d_edges, c->d_planes, c->d_sel_sharp, c->d_sel_flat,
                   c->d_grid_sorted3[0], c->d_grid_sorted3[1], c->d_grid_sorted2[0], c->d_grid_sorted2[1], c->d_grid_start3[0], c->d_grid_start3[1],
@@ -616,6 +627,7 @@ int aloam_cloud_size(aloam_ctx* c, int seq, int which) {
   DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
+  if (which == ALOAM_CLOUD_FULL && (rc = ensure_dense(c))) return rc;
   SeqMeta m;
   if ((rc = fetch_meta(c, seq, &m))) return rc;
   const float4* p; int n;
@@ -628,6 +640,7 @@ int aloam_get_cloud(aloam_ctx* c, int seq, int which, float* out, int cap_points
   DeviceScope device_scope(c);
   int rc = check_seq(c, seq);
   if (rc) return rc;
+  if (which == ALOAM_CLOUD_FULL && (rc = ensure_dense(c))) return rc;
   SeqMeta m;
   if ((rc = fetch_meta(c, seq, &m))) return rc;
   const float4* p; int n;
@@ -850,9 +863,9 @@ int aloam_profile_get(aloam_ctx* c, int kernel, double* total_ms, long long* lau
       const double Lcl = m[b].n_corner_last, Lsl = m[b].n_surf_last;
       switch (kernel) {
         case K_FIND_ENDS: bytes += 2 * 256 * 16; break;
-        case K_CLASSIFY: bytes += 16 * Nin + 5 * Nin; break;
-        case K_RING_OFFSETS: bytes += 8.0 * c->NB * c->R; break;
-        case K_SCATTER: bytes += 21 * Nin + 16 * N; break;
+        case K_CLASSIFY: bytes += 16 * Nin + 16 * N + 16.0 * (c->R + 1) * ((Nin + kBlockPts - 1) / kBlockPts); break;   // k_front: the sweep in, the slabs out, two granules per ring and block
+        case K_RING_OFFSETS: bytes += 12.0 * c->R; break;                                                                  // k_ring_starts
+        case K_SCATTER: bytes += 32 * N; break;                                                                            // k_dense_cloud (on demand)
         case K_RING_FEATURES: bytes += 16 * N + (c->debug_arrays ? 5 * N : 0) + 16 * (Fc + Lc + Fs + Ls); break;   // ring-ordered cloud in, the four feature clouds out (+ curvature / labels for the parity entry points)
         case K_BUILD_GRIDS: bytes += 16 * (Lcl + Lsl) + 48 * (Lcl + Lsl) + 12.0 * (c->grid_H[0] + c->grid_H[1]); break;   // read once, three sorted copies + three bucket tables out
         case K_TRANSFORM: bytes += 32 * (Fc + Fs); break;
@@ -894,6 +907,7 @@ static MapArgs map_args(aloam_ctx* c) {
   // after aloam_odometry_step's swap the sweep just processed is the "last" one: exactly what the odometry node publishes
   // as /laser_cloud_corner_last, /laser_cloud_surf_last and /velodyne_cloud_3 (reference src/laserOdometry.cpp:570-591)
   a.corner_last = c->d_less_sharp[1 - c->cur]; a.surf_last = c->d_less_flat[1 - c->cur]; a.full = c->d_cloud;
+  if (!c->dense_valid) { a.slabs = c->d_slabs; a.slab = c->slab; a.ringstart = c->d_ringstart; }   // the sweep just registered lives in its ring slabs; the dense copy is made only for who asks
   a.registered = c->d_registered;
   a.cubes = c->d_cubes; a.pool_cap = c->map_pool; a.tab = c->d_maptab;
   for (int k = 0; k < 2; ++k) {
@@ -1127,6 +1141,7 @@ int aloam_set_full_cloud(aloam_ctx* c, int seq, const float* cloud, int n) {
   int rc = check_seq(c, seq);
   if (rc) return rc;
   if (n < 0 || n > c->cap) { c->err = "cloud too large"; return ALOAM_E_CAPACITY; }
+  if ((rc = ensure_dense(c))) return rc;                // the other sequences' clouds of the last registration, before this one is replaced
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (n) HIP_TRY(c, hipMemcpy(c->d_cloud + (size_t)seq * c->cap, cloud, sizeof(float4) * n, hipMemcpyHostToDevice));
   SeqMeta m;

@@ -10,7 +10,8 @@
 
 namespace aloam {
 
-constexpr int kBlockPts = 1024;        // points per classify / scatter workgroup (256 threads x 4)
+constexpr int kFrontSlots = 128 + 8;   // look-back granules per k_front block: one per ring (kMaxRings), slot R = halfPassed index
+constexpr int kBlockPts = 1024;        // points per k_front workgroup (256 threads x 4)
 constexpr int kMaxRings = 128;
 constexpr int kSectors = 6;            // reference src/scanRegistration.cpp:282
 constexpr int kSharpPerSector = 2;     // :301
@@ -56,12 +57,12 @@ struct RegArgs {
   int ring_from_field;
   float min_range;
   SeqMeta* meta;             // [B]
-  int8_t* ringid;            // [B][cap]
-  float* ori;                // [B][cap] raw -atan2f(y,x)
-  int* hist;                 // [B][NB][R]
-  int* blockoff;             // [B][NB][R]
-  int* ringstart;            // [B][R+1]
-  float4* cloud;             // [B][cap] ring-ordered
+  float4* slabs;             // [B][R][slab] ring-ordered points, ring r of a sweep in its own slab (k_front)
+  int slab;                  // points per slab (>= the longest ring k_ring_features accepts)
+  unsigned long long* front_lb;   // [B][NB][kFrontSlots] {epoch, state, value} granules of k_front's look-back over the blocks of a sweep
+  int* front_ticket;         // [B] blocks of the sweep handed out so far (k_front takes, k_ring_starts resets)
+  int* ringstart;            // [B][R+1] start of every ring in the DENSE numbering (scanStartInd - 5)
+  float4* cloud;             // [B][cap] ring-ordered, dense: written by k_dense_cloud when a consumer of the full cloud asks
   float* curv;               // [B][cap]
   int8_t* label;             // [B][cap]
   unsigned long long* lookback;   // [B][4][R] {launch epoch, count} granules: points per ring and output class (k_ring_features)

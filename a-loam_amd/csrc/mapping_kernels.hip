@@ -1585,6 +1585,19 @@ __global__ __launch_bounds__(256) void k_map_register(MapArgs a) {
   a.registered[(long long)b * a.cap + i] = associate_to_map(a.full[(long long)b * a.cap + i], par);
 }
 
+// the same from the ring slabs of scan registration (k_front): ring r of the sweep, written at the ring's place in the dense numbering
+__global__ __launch_bounds__(256) void k_map_register_slabs(MapArgs a) {
+  const int r = blockIdx.x, b = blockIdx.y;
+  const int start = a.ringstart[b * (a.R + 1) + r], n = a.ringstart[b * (a.R + 1) + r + 1] - start;
+  const MapSeq& ms = a.seq[b];
+  double par[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) par[k] = ms.par[k];
+  const float4* src = a.slabs + ((long long)b * a.R + r) * a.slab;
+  float4* dst = a.registered + (long long)b * a.cap + start;
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = associate_to_map(src[i], par);
+}
+
 // =======================================================================================================
 // pool occupancy report (host-side pool growth, aloam_capi.hip map_ensure_capacity)
 // =======================================================================================================
@@ -1698,7 +1711,10 @@ void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s) {
   hipLaunchKernelGGL(k_map_reserve, dim3(a.B, 2), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_map_scatter, dim3(a.B, 2), dim3(64), 0, s, a);
 }
-void launch_map_register(const MapArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_map_register, dim3((a.cap + 255) / 256, a.B), dim3(256), 0, s, a); }
+void launch_map_register(const MapArgs& a, hipStream_t s) {
+  if (a.slabs) hipLaunchKernelGGL(k_map_register_slabs, dim3(a.R, a.B), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(k_map_register, dim3((a.cap + 255) / 256, a.B), dim3(256), 0, s, a);
+}
 void launch_map_report(const MapArgs& a, int step, hipStream_t s) { hipLaunchKernelGGL(k_map_report, dim3(a.B, 2), dim3(256), 0, s, a, step); }
 
 }  // namespace aloam

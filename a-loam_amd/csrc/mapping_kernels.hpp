@@ -77,7 +77,8 @@ struct MapArgs {
   float line_res, plane_res;
   const float4* corner_last;     // [B][R*120]  /laser_cloud_corner_last
   const float4* surf_last;       // [B][cap]    /laser_cloud_surf_last
-  const float4* full;            // [B][cap]    /velodyne_cloud_3
+  const float4* full;            // [B][cap]    /velodyne_cloud_3, dense (set from outside, or made by k_dense_cloud)
+  const float4* slabs; int slab; const int* ringstart;   // ... or, straight from scan registration: one slab per ring + the dense start of every ring (slabs == nullptr: use `full`)
   float4* registered;            // [B][cap]    /velodyne_cloud_registered
   CubeDesc* cubes;               // [B][2][kMapCubes]
   float4* pool[2];               // [B][pool_cap]
@@ -115,7 +116,7 @@ void launch_map_grid(const MapArgs& a, hipStream_t s);
 void launch_map_associate(const MapArgs& a, int iter, hipStream_t s);
 void launch_map_solve(const MapArgs& a, int iter, bool last, hipStream_t s);
 void launch_map_insert(const MapArgs& a, float4* staging, hipStream_t s);   // staging: 2 pools per sequence
-void launch_map_register(const MapArgs& a, hipStream_t s);
+void launch_map_register(const MapArgs& a, hipStream_t s);   // reads the slabs when a.slabs is set, the dense cloud otherwise
 void launch_map_report(const MapArgs& a, int step, hipStream_t s);
 int prepare_reference_order();                                                                  // reference_order_kernels.hip
 void launch_voxel_filter_reference_order(const VoxArgs& v, const MapArgs& a, bool stacks, hipStream_t s);

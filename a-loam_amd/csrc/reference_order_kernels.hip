@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kLitThreads) void k_less_flat_reference_order(RegAr
   float* s_f = reinterpret_cast<float*>(s_chunk + 3 * kRingChunkMax);
   unsigned short* member = reinterpret_cast<unsigned short*>(s_f + 8 + 24);   // [kMaxRing + 1] element of the m-th member (behind s_i)
   int* s_i = reinterpret_cast<int*>(s_f + 8);
-  const float4* cloud = a.cloud + (long long)b * a.cap + start + 5;
+  const float4* cloud = a.slabs + ((long long)b * a.R + r) * a.slab + 5;
   const int8_t* label = a.label + (long long)b * a.cap + start + 5;
   // lessFlatScan: every element whose label is <= 0, in element order (:392-398)
   int base = 0;

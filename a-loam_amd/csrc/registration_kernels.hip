@@ -3,10 +3,10 @@
 // Replaces the body of laserCloudHandler (reference src/scanRegistration.cpp:127-411) for a BATCH of
 // independent sweeps.  Kernel <-> reference map:
 //   k_find_ends       :136-153   first / last kept point, startOri / endOri
-//   k_classify        :85-112,160-236  NaN + range filter, ring id, raw azimuth, halfPassed flip index,
-//                                per-block ring histograms
-//   k_ring_offsets    :246-252   ring start offsets (exclusive scans of the histograms over the blocks, lanes across the rings)
-//   k_scatter         :208-241   relTime -> intensity, STABLE per-ring compaction into the ring-ordered cloud
+//   k_front           :85-112,156-241  the front end in one pass: NaN + range filter, ring id, azimuth, halfPassed, relTime -> intensity and
+//                                the STABLE per-ring compaction into one slab per ring (decoupled look-back over the blocks of a sweep)
+//   k_ring_starts     :246-252   ring lengths -> start of every ring in the reference's dense numbering, cloud size
+//   k_dense_cloud     :246-252   the dense ring-by-ring cloud from the slabs, only when a consumer of the full cloud asks
 //   k_ring_features   :256-407   one workgroup per (sweep, ring): 11-tap curvature from alternating 266-point LDS
 //                                tiles; std::sort + greedy corner / flat picking with neighbour suppression evaluated as
 //                                an iterative arg-max per sector (no sort); less-flat gather + 0.2 m voxel centroids
@@ -119,122 +119,88 @@ __device__ __forceinline__ int ring_of(const float4& p, int R, int ring_from_fie
 }
 
 // -------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_classify(RegArgs a) {
-  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+// The front end in ONE pass over the sweep (reference src/scanRegistration.cpp:156-252): ring id, azimuth, halfPassed, relTime -> intensity and
+// the stable per-ring compaction, each point read once and written once.  (Rounds 1 - 5 used two passes - classify into ring id / azimuth arrays
+// and block histograms, a scan, then a scatter that read the sweep again: 1.67 ms per 1024 sweeps; the arithmetic and the traffic of this
+// kernel alone were measured at 1.04 ms.)  What makes one pass possible:
+//   * ring r of a sweep owns a SLAB of `slab` points (slab >= the longest ring k_ring_features accepts), so where a point goes depends only on
+//     how many points of its ring came before it, not on how long the other rings turn out to be; the dense concatenation the reference
+//     publishes (/velodyne_cloud_2) is made from the slabs only when somebody asks for it (k_dense_cloud);
+//   * "how many came before" = rank inside the workgroup's 1024 points (wave ballots, the 16 (round, wave) counts scanned in LDS) + the sum over
+//     the blocks in front, by decoupled look-back: every block publishes per ring ONE 8-byte granule {epoch, state, value} - first its own count
+//     (state A), then, once it knows what lies in front of it, the inclusive prefix (state P) - and a block walks back over the granules of its
+//     predecessors, adding A's until it meets a P.  The halfPassed flip index (:220-223), a running minimum, travels the same way in slot R;
+//   * WHICH block a workgroup takes is a ticket drawn when it starts, so a block only ever waits for workgroups that are already running
+//     (the same argument as for the ring tickets of k_ring_features).  The launch is sweep-major (blockIdx.x = sweep), so the predecessor of
+//     a block was dispatched a whole batch earlier and has normally published long ago; at batch 1 the blocks of the sweep run side by side
+//     and the walk is a chain of up to NB / 2 granule reads.
+constexpr int kGatherSpinLimit = 1 << 20;                                     // polls of a look-back wait before it gives up (~1 s): a fault must not hang the stream
+__device__ __forceinline__ void front_publish(unsigned long long* g, unsigned epoch, unsigned prefix, int value) {
+  __hip_atomic_store(g, ((unsigned long long)((epoch << 1) | prefix) << 32) | (unsigned)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// exclusive prefix (sum or minimum) over the blocks in front of block `blk`; publishes this block's aggregate and inclusive prefix
+template <bool MIN>
+__device__ __forceinline__ int front_lookback(unsigned long long* slot0, int blk, unsigned epoch, int local, int* err) {   // slot0: granule of block 0 for this slot
+  constexpr int identity = MIN ? 0x7fffffff : 0;
+  unsigned long long* mine = slot0 + (long long)blk * kFrontSlots;
+  if (blk == 0) { front_publish(mine, epoch, 1u, local); return identity; }
+  front_publish(mine, epoch, 0u, local);
+  int acc = identity;
+  for (int t = blk - 1; t >= 0; --t) {
+    unsigned long long g;
+    int spins = 0;
+    while ((unsigned)((g = __hip_atomic_load(slot0 + (long long)t * kFrontSlots, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 33) != (epoch & 0x7fffffffu)) {
+      if (++spins > kGatherSpinLimit) { atomicOr(err, kErrInternal); g = (1ull << 32) | (unsigned)identity; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const int v = (int)(unsigned)g;
+    acc = MIN ? (v < acc ? v : acc) : acc + v;
+    if ((g >> 32) & 1ull) break;
+  }
+  front_publish(mine, epoch, 1u, MIN ? (local < acc ? local : acc) : acc + local);
+  return acc;
+}
+
+// Measured at batch 1024 (A/B on one box): 1.13 ms (1.15 without the eight-waves hint, which costs six spilled registers); block-major launch order
+// 1.59 ms (the look-back chains); with the waits compiled out 1.07 ms: the look-back costs 0.06 ms.  Before: k_classify 0.89 + k_ring_offsets 0.02 + k_scatter 0.76.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8))) void k_front(RegArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_cnt[16][kMaxRings];        // [round * 4 + wave][ring]: points of that ring in that wave's round -> offsets inside the ring's slab
+  __shared__ int s_half, s_ticket;
+  if (tid == 0) { s_ticket = atomicAdd(a.front_ticket + b, 1); s_half = 0x7fffffff; }
+  for (int q = tid; q < 16 * kMaxRings; q += 256) (&s_cnt[0][0])[q] = 0;
+  __syncthreads();
+  const int blk = s_ticket;
   const SeqMeta m = a.meta[b];
   const int n = m.n_in < a.cap ? m.n_in : a.cap;
-  if (blk * kBlockPts >= n && blk > 0) {      // still publish an empty histogram
-    for (int r = tid; r < a.R; r += 256) a.hist[((long long)b * a.NB + blk) * a.R + r] = 0;
-    return;
-  }
+  if (blk * kBlockPts >= n) return;            // (every later ticket of the sweep returns here too: nobody waits for this block)
   const char* in = a.in + (long long)b * a.seq_stride;
-  __shared__ int s_hist[kMaxRings];
-  __shared__ int s_half;
-  if (tid < kMaxRings) s_hist[tid] = 0;
-  if (tid == 0) s_half = 0x7fffffff;
-  __syncthreads();
-  const float startOri = m.start_ori;
+  const float startOri = m.start_ori, endOri = m.end_ori;
+  int ring[4], rank[4];
+  float4 p[4];
+  float ori[4];
   int myhalf = 0x7fffffff;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = blk * kBlockPts + k * 256 + tid;
-    int ring = -1;
-    float ori = 0.f;
+    ring[k] = -1;
+    p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ori[k] = 0.f;
     if (i < n) {
-      const float4 p = load_point(in, i, a.pt_stride);
-      if (point_kept(p, a.min_range)) {
-        ring = ring_of(p, a.R, a.ring_from_field);
-        if (ring >= 0) {
-          ori = -atan2f_port(p.y, p.x);                                                     // :208
-          float o1 = ori;                                                                   // branch taken while !halfPassed
+      const float4 q = load_point(in, i, a.pt_stride);
+      if (point_kept(q, a.min_range)) {
+        ring[k] = ring_of(q, a.R, a.ring_from_field);
+        if (ring[k] >= 0) {
+          p[k] = q;
+          ori[k] = -atan2f_port(q.y, q.x);                                                  // :208
+          float o1 = ori[k];                                                                // branch taken while !halfPassed
           if ((double)o1 < (double)startOri - M_PI / 2) o1 = (float)((double)o1 + 2 * M_PI);          // :211-214
           else if ((double)o1 > (double)startOri + M_PI * 3 / 2) o1 = (float)((double)o1 - 2 * M_PI); // :215-218
           if ((double)(o1 - startOri) > M_PI && i < myhalf) myhalf = i;                      // :220-223
         }
       }
-      a.ringid[(long long)b * a.cap + i] = (int8_t)ring;
-      a.ori[(long long)b * a.cap + i] = ori;
-    }
-    // wave-aggregated histogram update: one LDS atomic per distinct ring in the wave
-    unsigned long long todo = __ballot(ring >= 0);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int r = __shfl(ring, leader, 64);
-      const unsigned long long same = __ballot(ring == r);
-      if (lane == leader) atomicAdd(&s_hist[r], __popcll(same));
-      todo &= ~same;
     }
   }
-  // block-wide min of the halfPassed flip index
-  for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_down(myhalf, d, 64); myhalf = o < myhalf ? o : myhalf; }
-  if (lane == 0 && myhalf != 0x7fffffff) atomicMin(&s_half, myhalf);
-  __syncthreads();
-  if (tid == 0 && s_half != 0x7fffffff) atomicMin(&a.meta[b].half_idx, s_half);
-  for (int r = tid; r < a.R; r += 256) a.hist[((long long)b * a.NB + blk) * a.R + r] = s_hist[r];
-}
-
-// -------------------------------------------------------------------------------------------------------
-// Exclusive scan over the blocks of every ring.  hist is [block][ring]: thread (chunk, ring) walks its chunk of consecutive blocks,
-// so the lanes of a wave always touch consecutive rings of one block row (coalesced; the round-2 kernel put the lanes across blocks,
-// a 256 / 512-byte stride that fetched 5 - 9 times the table at 128 rings).  Chunk totals meet in LDS, one thread per ring chains them.
-__global__ __launch_bounds__(1024) void k_ring_offsets(RegArgs a) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  __shared__ int s_chunk[1024];                       // [chunk][ring] totals -> exclusive starts of the chunks
-  __shared__ int s_cnt[kMaxRings];
-  const int n = a.meta[b].n_in < a.cap ? a.meta[b].n_in : a.cap;
-  const int nb = (n + kBlockPts - 1) / kBlockPts;
-  int rp = 1;
-  while (rp < a.R) rp <<= 1;                          // rings padded to a power of two <= 128
-  const int nchunk = 1024 / rp, r = tid & (rp - 1), chunk = tid / rp;
-  const int per = (nb + nchunk - 1) / nchunk, b0 = chunk * per, b1 = min(nb, b0 + per);
-  const long long base = (long long)b * a.NB * a.R;
-  int sum = 0;
-  if (r < a.R) for (int blk = b0; blk < b1; ++blk) sum += a.hist[base + (long long)blk * a.R + r];
-  s_chunk[tid] = sum;
-  __syncthreads();
-  if (tid < a.R) {
-    int run = 0;
-    for (int c = 0; c < nchunk; ++c) { const int v = s_chunk[c * rp + tid]; s_chunk[c * rp + tid] = run; run += v; }
-    s_cnt[tid] = run;
-  }
-  __syncthreads();
-  if (r < a.R) {
-    int run = s_chunk[tid];
-    for (int blk = b0; blk < b1; ++blk) { const long long o = base + (long long)blk * a.R + r; const int h = a.hist[o]; a.blockoff[o] = run; run += h; }
-  }
-  if (tid == 0) {
-    int run = 0;
-    for (int q = 0; q < a.R; ++q) { a.ringstart[b * (a.R + 1) + q] = run; run += s_cnt[q]; }
-    a.ringstart[b * (a.R + 1) + a.R] = run;
-    a.meta[b].n_cloud = run;
-  }
-}
-
-// -------------------------------------------------------------------------------------------------------
-// Stable compaction into the ring-ordered cloud.  A workgroup owns 1024 consecutive points = 4 rounds of 256; the order of the
-// points of one ring inside the block is (round, wave, lane).  All four rounds are ranked first (wave ballots), one LDS pass turns
-// the 16 (round, wave) counts of every ring into offsets, then every point is stored: three barriers per block, and the loads of
-// all four rounds are in flight together.
-__global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
-  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const SeqMeta m = a.meta[b];
-  const int n = m.n_in < a.cap ? m.n_in : a.cap;
-  if (blk * kBlockPts >= n) return;
-  const char* in = a.in + (long long)b * a.seq_stride;
-  __shared__ int s_cnt[16][kMaxRings];        // [round * 4 + wave][ring]: points of that ring in that wave's round -> offsets
-  for (int q = tid; q < 16 * kMaxRings; q += 256) (&s_cnt[0][0])[q] = 0;
-  int ring[4], rank[4];
-  float4 p[4];
-  float ori[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = blk * kBlockPts + k * 256 + tid;
-    ring[k] = (i < n) ? (int)a.ringid[(long long)b * a.cap + i] : -1;
-    p[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ori[k] = 0.f;
-    if (ring[k] >= 0) { p[k] = load_point(in, i, a.pt_stride); ori[k] = a.ori[(long long)b * a.cap + i]; }
-  }
-  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     // rank among the same-ring lanes of this wave (stable: lower lane = earlier point)
@@ -249,21 +215,31 @@ __global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
       todo &= ~same;
     }
   }
+  for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_down(myhalf, d, 64); myhalf = o < myhalf ? o : myhalf; }
+  if (lane == 0 && myhalf != 0x7fffffff) atomicMin(&s_half, myhalf);
   __syncthreads();
-  if (tid < a.R) {                             // exclusive offsets over the 16 (round, wave) slots, on top of the block's base
-    int run = a.ringstart[b * (a.R + 1) + tid] + a.blockoff[((long long)b * a.NB + blk) * a.R + tid];
+  unsigned long long* lb = a.front_lb + (long long)b * a.NB * kFrontSlots;     // granule (block 0, slot 0) of this sweep
+  if (tid < a.R) {                             // offsets of the 16 (round, wave) slots inside the ring's slab, on top of what the blocks in front hold
+    int total = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) total += s_cnt[q][tid];
+    int run = front_lookback<false>(lb + tid, blk, a.epoch, total, &a.meta[b].err);
 #pragma unroll
     for (int q = 0; q < 16; ++q) { const int c = s_cnt[q][tid]; s_cnt[q][tid] = run; run += c; }
+  } else if (tid == 192) {                     // (wave 3: the rings occupy at most waves 0 and 1)
+    const int before = front_lookback<true>(lb + a.R, blk, a.epoch, s_half, &a.meta[b].err);
+    s_half = before < s_half ? before : s_half;
   }
   __syncthreads();
-  const float startOri = m.start_ori, endOri = m.end_ori;
+  const int half_idx = s_half;
+  float4* slabs = a.slabs + (long long)b * a.R * a.slab;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     if (ring[k] < 0) continue;
     const int i = blk * kBlockPts + k * 256 + tid;
     const int pos = s_cnt[k * 4 + wave][ring[k]] + rank[k];
     float o = ori[k];
-    if (i <= m.half_idx) {                                                                    // !halfPassed when visited
+    if (i <= half_idx) {                                                                      // !halfPassed when visited
       if ((double)o < (double)startOri - M_PI / 2) o = (float)((double)o + 2 * M_PI);
       else if ((double)o > (double)startOri + M_PI * 3 / 2) o = (float)((double)o - 2 * M_PI);
     } else {                                                                                  // :225-236
@@ -273,8 +249,49 @@ __global__ __launch_bounds__(256) void k_scatter(RegArgs a) {
     }
     const float relTime = (o - startOri) / (endOri - startOri);                               // :238
     const float inten = (float)((double)ring[k] + 0.1 * (double)relTime);                     // :239, scanPeriod 0.1
-    a.cloud[(long long)b * a.cap + pos] = make_float4(p[k].x, p[k].y, p[k].z, inten);
+    if (pos < a.slab) slabs[(long long)ring[k] * a.slab + pos] = make_float4(p[k].x, p[k].y, p[k].z, inten);   // (a ring longer than its slab: kErrRingCap, k_ring_starts)
   }
+}
+
+// After the pass: ring lengths = the inclusive prefixes of the sweep's last block; scanStartInd-like dense starts (ringstart, :246-252 in the
+// reference's dense numbering), the cloud size, the halfPassed index; the block tickets of the next launch.  One wave per sweep.
+__global__ __launch_bounds__(64) void k_ring_starts(RegArgs a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = a.meta[b].n_in < a.cap ? a.meta[b].n_in : a.cap;
+  const int nb = (n + kBlockPts - 1) / kBlockPts;
+  const unsigned long long* last = a.front_lb + ((long long)b * a.NB + (nb > 0 ? nb - 1 : 0)) * kFrontSlots;
+  int run = 0, err = 0;
+  for (int base = 0; base < a.R; base += 64) {
+    const int r = base + lane;
+    int c = 0;
+    if (r < a.R && nb > 0) {
+      const unsigned long long g = last[r];
+      if ((unsigned)(g >> 32) != (((a.epoch & 0x7fffffffu) << 1) | 1u)) err |= kErrInternal; else c = (int)(unsigned)g;
+      if (c > a.slab) { c = a.slab; err |= kErrRingCap; }
+    }
+    const int inc = wave_scan_i32<false>(c);
+    if (r < a.R) a.ringstart[b * (a.R + 1) + r] = run + inc - c;
+    run += __builtin_amdgcn_readlane(inc, 63);
+  }
+  if (err) atomicOr(&a.meta[b].err, err);
+  if (lane == 0) {
+    a.ringstart[b * (a.R + 1) + a.R] = run;
+    a.meta[b].n_cloud = run;
+    int half = 0x7fffffff;
+    if (nb > 0) { const unsigned long long g = last[a.R]; if ((unsigned)(g >> 32) == (((a.epoch & 0x7fffffffu) << 1) | 1u)) half = (int)(unsigned)g; }
+    a.meta[b].half_idx = half;
+    a.front_ticket[b] = 0;
+  }
+}
+
+// The reference's dense, ring-by-ring cloud (laserCloud, :246-252) from the slabs: only for the consumers of the FULL cloud (the getters, the
+// /velodyne_cloud_2 publisher, laserMapping's full-resolution input) - the feature kernels read the slabs.
+__global__ __launch_bounds__(256) void k_dense_cloud(RegArgs a) {
+  const int r = blockIdx.x, b = blockIdx.y;
+  const int start = a.ringstart[b * (a.R + 1) + r], n = a.ringstart[b * (a.R + 1) + r + 1] - start;
+  const float4* src = a.slabs + ((long long)b * a.R + r) * a.slab;
+  float4* dst = a.cloud + (long long)b * a.cap + start;
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
 // -------------------------------------------------------------------------------------------------------
@@ -298,7 +315,6 @@ __device__ __forceinline__ void publish_count(unsigned long long* slot, unsigned
 }
 // The wait is bounded: a fault in an earlier ring's workgroup must not hang the stream.  After kGatherSpinLimit polls (~1 s) the lane gives up, the count reads 0 and
 // kErrInternal is raised in the sequence's SeqMeta.err (aloam_synchronize reports it).
-constexpr int kGatherSpinLimit = 1 << 20;
 __device__ __forceinline__ int gather_counts(const unsigned long long* slots, int upto, unsigned epoch, int lane, int* err) {   // whole wave
   int sum = 0;
   for (int base = 0; base < upto; base += 64) {
@@ -670,7 +686,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPAD <= 204
   unsigned long long* gapw = reinterpret_cast<unsigned long long*>(s_scan);
   static_assert((ITEMS * 4 + 2) * 8 <= 256 * 4, "the gap bits fit the scan scratch");
   if (tid == 0) { s_misc[44] = 0; gapw[0] = ~0ull; gapw[ITEMS * 4 + 1] = ~0ull; }
-  const float4* cloud = a.cloud + (long long)b * a.cap + start;
+  const float4* cloud = a.slabs + ((long long)b * a.R + r) * a.slab;       // the ring's slab (k_front); `start` is its place in the dense numbering
   // ---- curvature (:256-266) + gap flags, kept in registers until the tiles are retired.  The ring goes through LDS in chunks
   // of 256 points (thread tid owns point it * 256 + tid = tile column tid + 5); the next chunk is fetched while this one is used.
   const int L = n - 11;                          // E - S
@@ -966,9 +982,9 @@ size_t ring_features_lds_bytes(int npad) {
 }
 
 void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s) { hipLaunchKernelGGL(k_find_ends, dim3(a.B), dim3(1024), 0, s, a, d_nin); }
-void launch_classify(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_classify, dim3(a.NB, a.B), dim3(256), 0, s, a); }
-void launch_ring_offsets(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ring_offsets, dim3(a.B), dim3(1024), 0, s, a); }
-void launch_scatter(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_scatter, dim3(a.NB, a.B), dim3(256), 0, s, a); }
+void launch_front(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_front, dim3(a.B, a.NB), dim3(256), 0, s, a); }   // sweep-major, see k_front   // sweep-major, see k_front
+void launch_ring_starts(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_ring_starts, dim3(a.B), dim3(64), 0, s, a); }
+void launch_dense_cloud(const RegArgs& a, hipStream_t s) { hipLaunchKernelGGL(k_dense_cloud, dim3(a.R, a.B), dim3(256), 0, s, a); }
 void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s) {
   const size_t lds = ring_features_lds_bytes(npad);
   if (npad <= 2048) hipLaunchKernelGGL(k_ring_features<2048>, dim3(a.B, a.R), dim3(256), lds, s, a, leaf);

@@ -5,9 +5,9 @@
 namespace aloam {
 size_t ring_features_lds_bytes(int npad);
 void launch_find_ends(const RegArgs& a, const int* d_nin, hipStream_t s);
-void launch_classify(const RegArgs& a, hipStream_t s);
-void launch_ring_offsets(const RegArgs& a, hipStream_t s);
-void launch_scatter(const RegArgs& a, hipStream_t s);
+void launch_front(const RegArgs& a, hipStream_t s);
+void launch_ring_starts(const RegArgs& a, hipStream_t s);
+void launch_dense_cloud(const RegArgs& a, hipStream_t s);
 void launch_ring_features(const RegArgs& a, int npad, float leaf, hipStream_t s);
 void launch_less_flat_reference_order(const RegArgs& a, int npad, float leaf, hipStream_t s);   // reference_order_kernels.hip
 }  // namespace aloam

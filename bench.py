@@ -342,7 +342,7 @@ def roofline_of(prof, steps, B, sensor, mapping):
             # the same command): wave-instructions per second against SIMDs x clock / 4
             sq = pm.get("sq", {})
             valu = {}
-            for pn in ("k_associate[plane]", "k_associate[corner]", "k_ring_features", "k_classify"):
+            for pn in ("k_associate[plane]", "k_associate[corner]", "k_ring_features", "k_front"):
                 kn = names(pn)
                 if stale or pn not in prof or not prof[pn]["launches"] or not kn or kn[0] not in sq or "SQ_INSTS_VALU" not in sq[kn[0]]:
                     continue

@@ -65,9 +65,13 @@ def test_ring_features_keeps_eight_workgroups_per_cu(registration):
     k = registration["k_ring_features<4096>"]                                  # the long-ring class: 38 KB of LDS, four workgroups per CU = four waves per SIMD; 86 measured
     assert k[".vgpr_count"] <= 88 and k[".vgpr_spill_count"] == 0 and k[".private_segment_fixed_size"] == 0, k
     assert occupancy_waves(k) >= 4, k
-    for name in ("k_classify", "k_scatter", "k_find_ends", "k_ring_offsets"):
+    for name in ("k_find_ends", "k_ring_starts", "k_dense_cloud"):
         k = registration[name]
         assert k[".vgpr_count"] <= 64 and k[".vgpr_spill_count"] == 0 and k[".sgpr_spill_count"] == 0, (name, k)
+    # the one-pass front end holds four points per thread (coordinates, ring, rank, azimuth): 68 registers unforced; at eight waves per SIMD it
+    # spills six of them and is still the faster build (1.13 against 1.15 ms at batch 1024)
+    k = registration["k_front"]
+    assert k[".vgpr_count"] <= 64 and k[".vgpr_spill_count"] <= 8 and k[".private_segment_fixed_size"] <= 40 and occupancy_waves(k) == 8, k
 
 
 def test_association_waves_fit_eight_per_simd(odometry):

@@ -4,7 +4,7 @@
     cell test, one (voxel index, first point) key per run, a STABLE radix sort on the voxel index only (7-bit digits, wave-striped
     element ownership, per-(digit, wave) counts scanned digit-major, rank among the equal digits of a row), voxel heads, members
     added in input order — against the oracle's voxel filter (canonical order) bit for bit;
-  * k_ring_offsets (registration_kernels.hip): the chunked column scan of the [block][ring] histograms;
+  * k_front (registration_kernels.hip): the decoupled look-back over the blocks of a sweep (per-ring counts, halfPassed index);
   * k_build_grids_fused (odometry_kernels.hip): three bucket tables as 16-bit counters packed two to a word — counting and the
     fetch-add of running offsets never carry from the low half into the high half while a cloud has at most 65535 points;
   * k_map_fit / k_map_solve (mapping_kernels.hip): valid factor records compacted per tile of 256 stack points and addressed densely
@@ -128,34 +128,67 @@ def test_lds_voxel_filter_model_equals_the_oracle_filter(O, kind):
     assert got.shape == ref.shape and np.array_equal(got.view(np.uint32), ref.view(np.uint32)), kind
 
 
-# ------------------------------------------------------------------------------------------------ k_ring_offsets
-@pytest.mark.parametrize("R,nb", [(16, 29), (64, 128), (128, 256), (51, 7), (64, 1)])
-def test_chunked_column_scan_of_the_ring_histograms(R, nb):
-    rng = np.random.default_rng(R * 1000 + nb)
+# ------------------------------------------------------------------------------------------------ k_front's look-back over the blocks of a sweep
+@pytest.mark.parametrize("R,nb,seed", [(16, 29, 0), (64, 128, 1), (128, 40, 2), (51, 7, 3), (64, 1, 4)])
+def test_decoupled_lookback_over_the_blocks_of_a_sweep(R, nb, seed):
+    """registration_kernels.hip front_lookback: every block publishes per ring one granule - first its own count (state A), then the inclusive prefix
+    (state P) - and walks back over its predecessors, adding A's until it meets a P; slot R carries the halfPassed index as a running minimum.
+    Blocks advance in a RANDOM interleaving (one granule read or one publication at a time, a block only ever started after its predecessors drew
+    their tickets); whatever the schedule, every block ends up with the exclusive prefix over the blocks in front of it."""
+    rng = np.random.default_rng(seed)
     hist = rng.integers(0, 40, (nb, R))
-    rp = 1
-    while rp < R:
-        rp <<= 1
-    nchunk = 1024 // rp
-    per = (nb + nchunk - 1) // nchunk
-    chunk_sum = np.zeros((nchunk, rp), np.int64)
-    for tid in range(1024):
-        r, chunk = tid & (rp - 1), tid // rp
-        b0, b1 = chunk * per, min(nb, chunk * per + per)
-        if r < R:
-            chunk_sum[chunk, r] = hist[b0:b1, r].sum()
-    chunk_start = np.cumsum(chunk_sum, axis=0) - chunk_sum
-    blockoff = np.zeros((nb, R), np.int64)
-    for tid in range(1024):
-        r, chunk = tid & (rp - 1), tid // rp
-        b0, b1 = chunk * per, min(nb, chunk * per + per)
-        if r < R:
-            run = chunk_start[chunk, r]
-            for blk in range(b0, b1):
-                blockoff[blk, r] = run
-                run += hist[blk, r]
-    assert np.array_equal(blockoff, np.cumsum(hist, axis=0) - hist)
-    assert np.array_equal(chunk_sum.sum(0)[:R], hist.sum(0))                        # the ring totals ringstart is built from
+    half = np.where(rng.random(nb) < 0.2, rng.integers(0, 100000, nb), 0x7fffffff)
+    want = np.cumsum(hist, axis=0) - hist
+    want_half = np.concatenate([[0x7fffffff], np.minimum.accumulate(half)[:-1]])
+    A, P = 1, 2
+    state = np.zeros((nb, R + 1), np.int64)
+    value = np.zeros((nb, R + 1), np.int64)
+    got = np.zeros((nb, R + 1), np.int64)
+    # per (block, slot) program counter: 0 = publish aggregate (or prefix for block 0), 1 = walking back at `t`, 2 = done
+    pc = np.zeros((nb, R + 1), np.int64)
+    t = np.zeros((nb, R + 1), np.int64)
+    acc = np.zeros((nb, R + 1), np.int64)
+    local = np.concatenate([hist, half[:, None]], axis=1)
+    started = 0
+    steps = 0
+    while (pc < 2).any():
+        steps += 1
+        assert steps < 10_000_000
+        if started < nb and (rng.random() < 0.3 or not ((pc[:started] < 2).any())):
+            started += 1                                                          # the next ticket is drawn
+            continue
+        live = np.argwhere(pc[:started] < 2)
+        blk, slot = live[rng.integers(len(live))]
+        is_min = slot == R
+        ident = 0x7fffffff if is_min else 0
+        if pc[blk, slot] == 0:
+            if blk == 0:
+                state[blk, slot], value[blk, slot] = P, local[blk, slot]
+                got[blk, slot] = ident
+                pc[blk, slot] = 2
+            else:
+                state[blk, slot], value[blk, slot] = A, local[blk, slot]
+                acc[blk, slot], t[blk, slot], pc[blk, slot] = ident, blk - 1, 1
+        else:
+            tt = t[blk, slot]
+            if state[tt, slot] == 0:
+                continue                                                          # not published yet: the lane spins
+            v = value[tt, slot]
+            acc[blk, slot] = min(acc[blk, slot], v) if is_min else acc[blk, slot] + v
+            if state[tt, slot] == P or tt == 0:
+                assert state[tt, slot] == P or tt > 0
+                if state[tt, slot] != P:
+                    t[blk, slot] = tt - 1
+                    continue
+                got[blk, slot] = acc[blk, slot]
+                incl = min(acc[blk, slot], local[blk, slot]) if is_min else acc[blk, slot] + local[blk, slot]
+                state[blk, slot], value[blk, slot] = P, incl
+                pc[blk, slot] = 2
+            else:
+                t[blk, slot] = tt - 1
+    assert np.array_equal(got[:, :R], want)
+    assert np.array_equal(got[:, R], want_half)
+    assert np.array_equal(value[nb - 1, :R], hist.sum(0))                          # what k_ring_starts reads: the ring lengths
 
 
 # ------------------------------------------------------------------------------------------------ packed 16-bit bucket tables

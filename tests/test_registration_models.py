@@ -1,9 +1,9 @@
 """CPU models of the arguments the round-2 registration kernels rest on (no GPU, no oracle):
 
-* k_classify's ring id: an f32 evaluation of the elevation angle decides the ring wherever the decision is the same 2e-4 degrees
+* k_front's ring id: an f32 evaluation of the elevation angle decides the ring wherever the decision is the same 2e-4 degrees
   below and above it; the f64 expression of reference src/scanRegistration.cpp:166 decides elsewhere.  Claim: identical rings.
 * k_ring_features' voxel indices from packed integer cells == pcl::VoxelGrid's float arithmetic (floor(p * inv) - floor(min * inv)).
-* k_scatter's offsets: ranking four rounds first and scanning the 16 (round, wave) counts == the sequential stable compaction.
+* k_front's offsets inside a block: ranking four rounds first and scanning the 16 (round, wave) counts == the sequential stable compaction.
 * k_ring_features' final-place output: offsets gathered from the published ring counts == plain concatenation ring by ring.
 """
 import numpy as np
