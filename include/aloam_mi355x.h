@@ -61,7 +61,8 @@ typedef struct aloam_config {
 
 /* Which cloud of a sequence (topic names of reference src/scanRegistration.cpp:480-488, src/laserOdometry.cpp:205-209). */
 enum {
-  ALOAM_CLOUD_FULL = 0,        /* /velodyne_cloud_2        ring-ordered laserCloud                 */
+  ALOAM_CLOUD_FULL = 0,        /* /velodyne_cloud_2        ring-ordered laserCloud (src/scanRegistration.cpp:246-252).  The device keeps one slab per
+                                  ring; the dense ring-by-ring cloud is assembled when this id is first asked for after a registration  */
   ALOAM_CLOUD_SHARP = 1,       /* /laser_cloud_sharp                                              */
   ALOAM_CLOUD_LESS_SHARP = 2,  /* /laser_cloud_less_sharp                                         */
   ALOAM_CLOUD_FLAT = 3,        /* /laser_cloud_flat                                               */

@@ -157,6 +157,29 @@ def test_teacher_forced_odometry_step(O, binding, sequence):
     gpu.close()
 
 
+def test_sweeps_in_firing_order_through_the_one_pass_front_end(O, binding, sequence):
+    """The message order of a real Velodyne driver: all lasers of a firing, then the next azimuth - every wave of k_front sees 64 different rings,
+    every 1024-point block adds 16 points to each ring's slab, and halfPassed (src/scanRegistration.cpp:220-223) flips in the MIDDLE of the sweep,
+    i.e. in a block whose predecessors carry it through the look-back.  Three different sweeps in one batch (the blocks of several sweeps interleave
+    in the launch), each against the oracle: clouds, ring ranges and features bit for bit, and the dense full cloud only made on request."""
+    scans, _, _, model = sequence("HDL-64", 3, seed=5, columns=512)
+    R = model.n_scans
+    fired = []
+    for x in scans:
+        assert len(x) == R * 512                                           # the arena returns every ray: ring-major [R][512]
+        fired.append(np.ascontiguousarray(x.reshape(R, 512, 4).transpose(1, 0, 2).reshape(-1, 4)))
+    fired[2] = fired[2][: 23 * 1024 + 517]                                 # a ragged last block; rings of unequal length
+    gpu = _mk(binding, model, batch=3, max_points=R * 512 + 64)
+    gpu.scan_register(fired)
+    for b, x in enumerate(fired):
+        orc = O.Oracle(n_scans=R, min_range=model.min_range)
+        fo = orc.scan_register(x)
+        _assert_features_equal(fo, gpu.features(b), ("fired", b))
+        so, co = orc.ring_ranges(); sg, cg = gpu.ring_ranges(b)
+        assert np.array_equal(so, sg) and np.array_equal(co, cg)
+    gpu.close()
+
+
 def test_input_layouts_and_nan_filter(O, binding, syn, sequence):
     """stride-32 PointCloud2 records == stride-16; NaN returns are dropped like removeNaNFromPointCloud does."""
     scans, R, t, model = sequence("VLP-16", 1, seed=8, nan_fraction=0.03)
