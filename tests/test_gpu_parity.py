@@ -180,6 +180,37 @@ def test_sweeps_in_firing_order_through_the_one_pass_front_end(O, binding, seque
     gpu.close()
 
 
+def test_dense_full_cloud_is_made_on_demand_and_mapping_reads_the_slabs(O, binding, sequence):
+    """The device keeps the registered sweep as one slab per ring; the reference's dense laserCloud (src/scanRegistration.cpp:246-252) is assembled when
+    somebody asks for it.  (i) Replacing ONE sequence's full cloud from outside must leave the other sequence's cloud of the last registration in
+    place; (ii) /velodyne_cloud_registered (src/laserMapping.cpp:836-846) is the same whether laserMapping's full-resolution input came straight
+    from the slabs (nobody asked for the dense cloud before the step) or from the dense copy (somebody did)."""
+    scans, _, _, model = sequence("HDL-64", 2, seed=6, columns=512)
+    orc = [O.Oracle(n_scans=model.n_scans, min_range=model.min_range) for _ in range(2)]
+    want = [orc[b].scan_register(scans[b])["cloud"] for b in range(2)]
+    gpu = _mk(binding, model, batch=2, max_points=len(scans[0]) + 64)
+    gpu.scan_register([scans[0], scans[1]])
+    other = np.ascontiguousarray(want[1][:1000][::-1])
+    gpu.set_full_cloud(other, seq=0)                                       # before anybody read the dense cloud
+    assert bits_equal(gpu.cloud(binding.CLOUD_FULL, 0), other)
+    assert bits_equal(gpu.cloud(binding.CLOUD_FULL, 1), want[1])
+    gpu.close()
+    reg = []
+    for ask_first in (False, True):
+        g = _mk(binding, model, batch=2, max_points=len(scans[0]) + 64)
+        g.mapping_enable(0.4, 0.8, pool_points=65536)
+        for k in range(2):
+            g.scan_register([scans[k], scans[1 - k]])
+            g.odometry_step()
+            if ask_first:
+                assert bits_equal(g.cloud(binding.CLOUD_FULL, 0), want[k])
+            g.mapping_step()
+        reg.append([g.map_cloud(binding.MAP_REGISTERED, b) for b in range(2)])
+        g.close()
+    for b in range(2):
+        assert len(reg[0][b]) == len(want[1 - b]) and bits_equal(reg[0][b], reg[1][b]), b
+
+
 def test_input_layouts_and_nan_filter(O, binding, syn, sequence):
     """stride-32 PointCloud2 records == stride-16; NaN returns are dropped like removeNaNFromPointCloud does."""
     scans, R, t, model = sequence("VLP-16", 1, seed=8, nan_fraction=0.03)
