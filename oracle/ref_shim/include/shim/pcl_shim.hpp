@@ -167,7 +167,12 @@ class VoxelGrid {
       float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f;
       for (size_t q = a; q < b; ++q) { const PointT& p = in.points[ev[q].pt]; sx += p.x; sy += p.y; sz += p.z; si += p.intensity; }
       const float n = static_cast<float>(b - a);
-      PointT o; o.x = sx / n; o.y = sy / n; o.z = sz / n; o.intensity = si / n;
+      PointT o;
+#ifdef SHIM_CENTROID_BY_RECIPROCAL   // tools/third_party_sensitivity.py: "what if the real PCL / Eigen pair scales the sums by 1 / n instead of dividing them"
+      { const float rn = 1.0f / n; o.x = sx * rn; o.y = sy * rn; o.z = sz * rn; o.intensity = si * rn; }
+#else
+      o.x = sx / n; o.y = sy / n; o.z = sz / n; o.intensity = si / n;
+#endif
       output.points.push_back(o);
       a = b;
     }
@@ -204,7 +209,11 @@ class KdTreeFLANN {
     best.reserve(k + 1);
     const float qv[3] = {q.x, q.y, q.z};
     search(0, qv, k, best);
+#ifdef SHIM_KNN_TIES_HIGHEST          // tools/third_party_sensitivity.py: equal distances resolved the other way round (FLANN's own order is its traversal order)
+    for (int j = 0; j < k; ++j) { k_indices[j] = -best[j].second; k_sqr_distances[j] = best[j].first; }
+#else
     for (int j = 0; j < k; ++j) { k_indices[j] = best[j].second; k_sqr_distances[j] = best[j].first; }
+#endif
     return k;
   }
  private:
@@ -237,7 +246,11 @@ class KdTreeFLANN {
         float diff = p.x - q[0]; d += diff * diff;
         diff = p.y - q[1]; d += diff * diff;
         diff = p.z - q[2]; d += diff * diff;
+#ifdef SHIM_KNN_TIES_HIGHEST
+        const std::pair<float, int> key(d, -i);
+#else
         const std::pair<float, int> key(d, i);
+#endif
         if (static_cast<int>(best.size()) == k && !(key < best.back())) continue;
         best.insert(std::upper_bound(best.begin(), best.end(), key), key);
         if (static_cast<int>(best.size()) > k) best.pop_back();
