@@ -104,7 +104,7 @@ def run(argv):
             counts[s::S, k] = x.shape[0]
         for b in range(s + S, B, S):
             hip.d2d(base + b * seq_stride, base + s * seq_stride, seq_stride)
-    gpu = binding.Aloam(n_scans=meta["n_scans"], min_range=meta["min_range"], ring_from_field=meta["ring_from_field"], batch=B, max_points=NP,
+    gpu = binding.Aloam(n_scans=meta["n_scans"], min_range=meta["min_range"], ring_from_field=meta["ring_from_field"], batch=B, max_points=NP + int(os.environ.get("ALOAM_AB_PAD", "0")),   # ALOAM_AB_PAD: per-sequence strides off the power of two
                         max_ring_points=2059 if meta["columns"] <= 2048 else 4107)
     if mapping:
         gpu.mapping_enable(0.4, 0.8, pool_points=262144)
