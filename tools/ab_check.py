@@ -92,7 +92,7 @@ def run(argv):
     meta = json.loads(str(z["meta"]))
     T, S = meta["frames"], meta["sequences"]
     NP = max(z[f"s{s}_f{k}"].shape[0] for s in range(S) for k in range(T))
-    NP = (NP + 255) // 256 * 256
+    NP = (NP + 255) // 256 * 256 + int(os.environ.get("ALOAM_AB_INPAD", "0"))   # ALOAM_AB_INPAD: the stored sweeps off the power-of-two stride too
     hip = Hip()
     seq_stride = T * NP * 16
     base = hip.malloc(B * seq_stride)
@@ -104,10 +104,10 @@ def run(argv):
             counts[s::S, k] = x.shape[0]
         for b in range(s + S, B, S):
             hip.d2d(base + b * seq_stride, base + s * seq_stride, seq_stride)
-    gpu = binding.Aloam(n_scans=meta["n_scans"], min_range=meta["min_range"], ring_from_field=meta["ring_from_field"], batch=B, max_points=NP + int(os.environ.get("ALOAM_AB_PAD", "0")),   # ALOAM_AB_PAD: per-sequence strides off the power of two
+    gpu = binding.Aloam(n_scans=meta["n_scans"], min_range=meta["min_range"], ring_from_field=meta["ring_from_field"], batch=B, max_points=NP - int(os.environ.get("ALOAM_AB_INPAD", "0")) + int(os.environ.get("ALOAM_AB_PAD", "0")),   # ALOAM_AB_PAD: per-sequence strides off the power of two
                         max_ring_points=2059 if meta["columns"] <= 2048 else 4107)
     if mapping:
-        gpu.mapping_enable(0.4, 0.8, pool_points=262144)
+        gpu.mapping_enable(0.4, 0.8, pool_points=262144 + int(os.environ.get("ALOAM_AB_POOLPAD", "0")))
     order, t, d = [], 0, 1                                       # ping-pong replay of the stored frames, like bench.py's frame_order
     for _ in range(steps):
         order.append(t)
