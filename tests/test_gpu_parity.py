@@ -180,6 +180,32 @@ def test_sweeps_in_firing_order_through_the_one_pass_front_end(O, binding, seque
     gpu.close()
 
 
+@pytest.mark.parametrize("name,columns,seed", [("VLP-16", 300, 11), ("HDL-32", 260, 12), ("HDL-64", 200, 13), ("HDL-64", 390, 14)])
+def test_front_end_on_shuffled_truncated_and_holed_sweeps(O, binding, sequence, name, columns, seed):
+    """k_front against the reference's sequential loop on inputs no sensor would send: the same sweep in ring-major order, in a RANDOM order (every
+    wave sees up to 64 rings, the stable rank of a point depends on every block in front of it, halfPassed flips wherever the order says), cut
+    off in the middle of a block, and with NaN / too-close returns sprinkled in - four different sequences in one batch, so that the tickets and
+    look-back granules of several sweeps interleave.  Clouds, ring ranges and the four feature clouds bit for bit."""
+    scans, _, _, model = sequence(name, 1, seed=seed, columns=columns)
+    x = scans[0]
+    rng = np.random.default_rng(seed)
+    variants = [x, x[rng.permutation(len(x))], x[: len(x) // 2 + 333], x.copy()]
+    holes = rng.random(len(x)) < 0.05
+    variants[3][holes, 0] = np.nan
+    variants[3][rng.random(len(x)) < 0.03, :3] *= 1e-3                      # inside minimum_range
+    variants[3] = variants[3][rng.permutation(len(x))]
+    gpu = _mk(binding, model, batch=4, max_points=len(x) + 64)
+    for rep in range(2):                                                   # twice: the second launch reuses tickets and granules (epoch tags)
+        gpu.scan_register(variants if rep == 0 else variants[::-1])
+        for b, v in enumerate(variants if rep == 0 else variants[::-1]):
+            orc = O.Oracle(n_scans=model.n_scans, min_range=model.min_range, ring_from_field=model.ring_from_field)
+            fo = orc.scan_register(v)
+            _assert_features_equal(fo, gpu.features(b), (name, rep, b))
+            so, co = orc.ring_ranges(); sg, cg = gpu.ring_ranges(b)
+            assert np.array_equal(so, sg) and np.array_equal(co, cg), (name, rep, b)
+    gpu.close()
+
+
 def test_dense_full_cloud_is_made_on_demand_and_mapping_reads_the_slabs(O, binding, sequence):
     """The device keeps the registered sweep as one slab per ring; the reference's dense laserCloud (src/scanRegistration.cpp:246-252) is assembled when
     somebody asks for it.  (i) Replacing ONE sequence's full cloud from outside must leave the other sequence's cloud of the last registration in
