@@ -83,7 +83,7 @@ def parse_args():
     ap.add_argument("--extra-steps", type=int, default=30)
     ap.add_argument("--repeat-to-seconds", type=float, default=1.0, help="after the K timed steps, time further identical K-step blocks until this many seconds are covered (0: off; always off with --no-extras); reported as repeated_blocks, never as `value`")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1024, help="independent sequences per GPU (measured: 256 -> 77 k sweeps/s, 512 -> 86 k, 1024 -> 90 k, 2048 -> 93 k)")
+    ap.add_argument("--batch", type=int, default=2048, help="independent sequences per GPU of the headline leg (round 6, kernel time per sequence: 1024 -> 8.72 us, 2048 -> 8.27, 4096 -> 8.27; 30 MB of HBM per sequence); the configs[2] / [3] comparison legs stay at min(batch, 1024)")
     ap.add_argument("--frames", type=int, default=6, help="stored sweeps per sequence (replayed ping-pong)")
     ap.add_argument("--sensor", default="HDL-64", help="headline workload sensor (HDL-64 = BASELINE configs[1]; ROWS128 = configs[3])")
     ap.add_argument("--mapping", action="store_true", help="headline workload = BASELINE configs[2]: scan-to-map refinement after every sweep")
@@ -233,12 +233,12 @@ def map_state(cx, n_seq=4):
     return out
 
 
-def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping, repeat_to_s=0.0, repeats_out=None):
+def timed_resident(torch, dist, world, ctxs, wl, steps, warmup, mapping, repeat_to_s=0.0, repeats_out=None, batch=None):
     """W untimed + exactly K timed steps with the inputs resident in HBM; per-kernel hipEvents on the context's own stream.
     `repeat_to_s` > 0: after the K timed steps (which alone make `value`), further identical blocks of exactly K steps are timed the
     same way (barrier + synchronize on both sides, MAX over ranks) until the blocks add up to that many seconds (at most 24 blocks), and
     their times are appended to `repeats_out` — the driver's `--steps 20` times 0.2 s, too short to say anything about spread."""
-    NC, BC = len(ctxs), wl.B // len(ctxs)
+    NC, BC = len(ctxs), (batch or wl.B) // len(ctxs)       # batch: only the first `batch` sequences of the workload (the comparison legs)
     order = frame_order(wl.T, warmup + steps)
     nin = {(k, c): wl.nin(k, c * BC, (c + 1) * BC) for k in range(wl.T) for c in range(NC)}
     base = wl.data.data_ptr()
@@ -751,17 +751,18 @@ def main():
     if extras and not args.mapping and args.sensor == "HDL-64":
         # ---- BASELINE.json configs[2]: the same sweeps with the scan-to-map refinement after every sweep
         steps2, warm2 = max(4, min(args.steps, args.extra_steps)), args.warmup
-        cx = wl.ctx(binding, B, local_rank)
+        Bx = min(B, 1024)                                  # the comparison legs keep the batch of the earlier rounds
+        cx = wl.ctx(binding, Bx, local_rank)
         cx.mapping_enable(0.4, 0.8, args.map_pool)
-        el2, prof2 = timed_resident(torch, dist, 1, [cx], wl, steps2, warm2, True)
+        el2, prof2 = timed_resident(torch, dist, 1, [cx], wl, steps2, warm2, True, batch=Bx)
         info = cx.map_info(0)
         cx.close()
         lat_map = latency(binding, wl, local_rank, max(30, args.latency_sweeps // 3), mapping=True)
         acc_map = accuracy_mapping(binding, wl, local_rank, args.map_pool) if not args.no_cpu_baseline else None
         out["workloads"] = {"configs[2] odometry + laserMapping": {
-            "workload": wl.describe(True), "value": round(B * steps2 / el2, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el2 / steps2, 4),
-            "steps": steps2, "warmup": warm2, "sequences_per_gpu": B, "map_pool_points": args.map_pool,
-            "roofline": roofline_of(prof2, steps2, B, "HDL-64", True), "map_state_seq0": {k: info[k] for k in ("frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack")},
+            "workload": wl.describe(True), "value": round(Bx * steps2 / el2, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el2 / steps2, 4),
+            "steps": steps2, "warmup": warm2, "sequences_per_gpu": Bx, "map_pool_points": args.map_pool,
+            "roofline": roofline_of(prof2, steps2, Bx, "HDL-64", True), "map_state_seq0": {k: info[k] for k in ("frame_count", "from_map_corner", "from_map_surf", "corner_stack", "surf_stack")},
             "latency": lat_map}}
         if acc_map is not None:
             out["workloads"]["configs[2] odometry + laserMapping"]["accuracy"] = acc_map
@@ -785,14 +786,14 @@ def main():
         torch.cuda.empty_cache()
         # ---- BASELINE.json configs[3]: 128 rings x 2048 columns stress (ring index from the 4th float)
         T3 = min(T, 4)
-        wl3 = Workload(syn, torch, "ROWS128", B, T3, rank, dev)
-        cx = wl3.ctx(binding, B, local_rank)
+        wl3 = Workload(syn, torch, "ROWS128", Bx, T3, rank, dev)
+        cx = wl3.ctx(binding, Bx, local_rank)
         el3, prof3 = timed_resident(torch, dist, 1, [cx], wl3, steps2, warm2, False)
         cx.close()
         out["workloads"]["configs[3] 128x2048 stress"] = {
-            "workload": wl3.describe(False), "value": round(B * steps2 / el3, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el3 / steps2, 4),
-            "steps": steps2, "warmup": warm2, "sequences_per_gpu": B, "points_per_sweep": wl3.NP,
-            "roofline": roofline_of(prof3, steps2, B, "ROWS128", False), "input_generation_s": round(wl3.gen_s, 2)}
+            "workload": wl3.describe(False), "value": round(Bx * steps2 / el3, 2), "unit": "scans/s", "ms_per_step": round(1e3 * el3 / steps2, 4),
+            "steps": steps2, "warmup": warm2, "sequences_per_gpu": Bx, "points_per_sweep": wl3.NP,
+            "roofline": roofline_of(prof3, steps2, Bx, "ROWS128", False), "input_generation_s": round(wl3.gen_s, 2)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -10,7 +10,7 @@ cd $R
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 python bench.py > $O/bench.log 2>&1; tail -c 600 $O/bench.log
 cd /tmp && export TMPDIR=/tmp
-for cfg in "headline:" "mapping:--mapping" "rows128:--sensor ROWS128" "travel:--travel --frames 24"; do
+for cfg in "headline:" "mapping:--mapping" "rows128:--sensor ROWS128 --batch 1024" "travel:--travel --frames 24 --batch 1024"; do   # the comparison workloads keep the batch of the earlier rounds
   name=${cfg%%:*}; args=${cfg#*:}
   rocprofv3 --kernel-trace --stats -d $O/stats_$name -o s -- python $R/bench.py --no-cpu-baseline --no-extras --steps 10 $args > $O/stats_$name.log 2>&1
   (cd $R && python tools/rocprof_summary.py $O/stats_$name/s_results.db $O/kernel_stats_$name.md "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline --no-extras --steps 10 $args" > /dev/null)
@@ -18,7 +18,7 @@ for cfg in "headline:" "mapping:--mapping" "rows128:--sensor ROWS128" "travel:--
 done
 cd $R
 bash tools/gpu_pmc.sh $TAG/pmc_headline --no-extras > /dev/null 2>&1
-for cfg in "mapping:--mapping" "rows128:--sensor ROWS128"; do
+for cfg in "mapping:--mapping" "rows128:--sensor ROWS128 --batch 1024"; do
   name=${cfg%%:*}; args=${cfg#*:}
   ( cd /tmp
     for c in FETCH_SIZE WRITE_SIZE; do

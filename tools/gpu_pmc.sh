@@ -28,7 +28,9 @@ lib = os.environ.get("ALOAM_MI355X_LIB", "$R/a-loam_amd/lib/libaloam_mi355x.so")
 sq = {k: dict({c: v[c] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES") if c in v},
               **{c: s2.get(k, {}).get(c) for c in ("SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_ANY") if s2.get(k, {}).get(c) is not None},
               avg_us=s2.get(k, {}).get("avg_us", v.get("avg_us"))) for k, v in s1.items()}
-json.dump({"batch": int(args[args.index("--batch") + 1]) if "--batch" in args else 1024, "mapping": "--mapping" in args,
+import re
+default_batch = int(re.search(r'"--batch", type=int, default=(\d+)', open("$R/bench.py").read()).group(1))
+json.dump({"batch": int(args[args.index("--batch") + 1]) if "--batch" in args else default_batch, "mapping": "--mapping" in args,
            "sensor": args[args.index("--sensor") + 1] if "--sensor" in args else "HDL-64",
            "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / two SQ groups, separate passes of python bench.py --no-cpu-baseline --steps 3 --warmup 1 $* (tools/gpu_pmc.sh $TAG)",

@@ -33,9 +33,11 @@ def main(tag, prefix):
         if os.path.exists(os.path.join(ROOT, "gpurun_out", name)):
             shutil.copyfile(os.path.join(ROOT, "gpurun_out", name), os.path.join(dst, f"{prefix}_{name}"))
     map_batch = next((w["sequences_per_gpu"] for k, w in json.loads(line).get("workloads", {}).items() if "steady-state" in k), 256)   # --mapping = the travelling workload
+    side_batch = next((w["sequences_per_gpu"] for k, w in json.loads(line).get("workloads", {}).items() if k.startswith("configs[3]")), 1024)   # --sensor ROWS128 / --travel runs of gpu_evidence.sh: --batch 1024
+    batch_of = {"headline": batch, "mapping": map_batch, "rows128": side_batch, "travel": side_batch}
     for cfg in ("headline", "mapping", "rows128", "travel"):
         if os.path.exists(os.path.join(src, f"kernel_stats_{cfg}.md")):
-            cp(f"kernel_stats_{cfg}.md", f"{prefix}_kernel_stats_{cfg}_b{map_batch if cfg == 'mapping' else batch}.md")
+            cp(f"kernel_stats_{cfg}.md", f"{prefix}_kernel_stats_{cfg}_b{batch_of[cfg]}.md")
     for extra in ("pmc_mapping_sq1.md", "pmc_mapping_tcp.md"):
         if os.path.exists(os.path.join(src, extra)):
             cp(extra, f"{prefix}_{extra[:-3]}_b{map_batch}.md")
@@ -45,11 +47,11 @@ def main(tag, prefix):
     traffic["headline"]["source"] += f"; profiles/{prefix}_pmc_fetch_headline_b{batch}.md, {prefix}_pmc_write_headline_b{batch}.md"
     for cfg, args, sensor in (("mapping", "--mapping", "HDL-64"), ("rows128", "--sensor ROWS128", "ROWS128")):
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            cp(f"pmc_{cfg}_{c}.md", f"{prefix}_pmc_{c.split('_')[0].lower()}_{cfg}_b{map_batch if cfg == 'mapping' else batch}.md")
+            cp(f"pmc_{cfg}_{c}.md", f"{prefix}_pmc_{c.split('_')[0].lower()}_{cfg}_b{batch_of[cfg]}.md")
         fj, wj = (json.load(open(os.path.join(src, f"pmc_{cfg}_{c}.json"))) for c in ("FETCH_SIZE", "WRITE_SIZE"))
-        traffic[cfg] = {"batch": map_batch if cfg == "mapping" else batch, "mapping": cfg == "mapping", "sensor": sensor, "lib_sha256": here,
+        traffic[cfg] = {"batch": batch_of[cfg], "mapping": cfg == "mapping", "sensor": sensor, "lib_sha256": here,
                         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of python bench.py --no-cpu-baseline --no-extras --steps 3 --warmup 1 {args} "
-                                  f"(tools/gpu_evidence.sh); profiles/{prefix}_pmc_fetch_{cfg}_b{batch}.md, {prefix}_pmc_write_{cfg}_b{batch}.md",
+                                  f"(tools/gpu_evidence.sh); profiles/{prefix}_pmc_fetch_{cfg}_b{batch_of[cfg]}.md, {prefix}_pmc_write_{cfg}_b{batch_of[cfg]}.md",
                         "fetch_kib": {k: v["FETCH_SIZE"] for k, v in fj.items() if "FETCH_SIZE" in v}, "write_kib": {k: v["WRITE_SIZE"] for k, v in wj.items() if "WRITE_SIZE" in v},
                         "avg_us": {k: v.get("avg_us") for k, v in fj.items()}}
     for cfg, name in (("headline", "pmc_traffic_latest.json"), ("mapping", "pmc_traffic_mapping.json"), ("rows128", "pmc_traffic_rows128.json")):
