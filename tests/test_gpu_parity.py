@@ -720,7 +720,7 @@ def test_eight_rank_bench_run(binding):
     """The driver's N = 8 launch shape, as far as a one-GPU box allows: `python bench.py --gpus 8` starts eight ranks (one process each,
     rendezvous on 127.0.0.1) that share the single device (ALOAM_BENCH_SHARED_GPU: gloo control plane), 16 sequences each, no data-path
     collective; rank 0 prints n_gpus = 8.  From the memory figures of the line and of a one-rank run: a rank's HBM footprint at the
-    default --batch 1024 and eight ranks' host memory must fit a real 8 x MI355X node (288 GB per GPU; the host's RAM)."""
+    default --batch 2048 and eight ranks' host memory must fit a real 8 x MI355X node (288 GB per GPU; the host's RAM)."""
     import json
     import subprocess
     import sys
@@ -740,7 +740,7 @@ def test_eight_rank_bench_run(binding):
     mem = one["memory"]
     per_seq = mem["hbm_bytes_per_sequence"]
     assert 5e6 < per_seq < 60e6, mem                                            # ~14 MB of state + 3 x 2.1 MB of stored sweeps
-    assert per_seq * 1024 + 4e9 < 288e9, mem                                    # a rank at the default batch on its own 288 GB GPU
+    assert per_seq * 2048 + 4e9 < 288e9, mem                                    # a rank at the default batch (2048) on its own 288 GB GPU
     if eight["memory"]["host_rss_bytes"]:
         assert 8 * eight["memory"]["host_rss_bytes"] < 0.8 * eight["memory"]["host_ram_bytes"], eight["memory"]
     out_dir = os.path.join(root, "gpurun_out")
